@@ -1,0 +1,184 @@
+/*
+ * ludwig_hip.h - C ABI of libludwig_hip.so, the MI355X (gfx950) collide-and-stream engine
+ * that drops in under OPEN_Ludwig's per-level time-step API.
+ *
+ * Every entry point names the reference interface it replaces (paths are relative to the
+ * reference repository root). The reference is Julia; the binding a maintainer adds is a
+ * `ccall` wrapper, shown in INTEGRATION.md and julia/LudwigHIP.jl.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host arrays are borrowed for the duration of the call.
+ *   - host arrays use the reference's memory layout (src/blocks.jl:118-150): Julia
+ *     column-major A[x,y,z,b,k] -> linear (x-1) + 8(y-1) + 64(z-1) + 512(b-1) + 512*n_blocks*(k-1);
+ *     index tables keep the reference's 1-based values with 0 = absent.
+ *   - every function returns LUDWIG_OK (0) or a negative LUDWIG_ERR_* code and never throws;
+ *     the message is available from ludwig_last_error() (thread-local).
+ *   - a LudwigLevel is not re-entrant; calls are asynchronous on the level's HIP stream and
+ *     ordered by it; ludwig_sync() is the reference's KernelAbstractions.synchronize.
+ *   - lattice tables (c, w, opp, mirror_y, mirror_z of src/physics_v2.jl:99-117) are compile-time
+ *     constants inside the library: k = (cx+1) + 3(cy+1) + 9(cz+1) (+1 in the reference).
+ */
+#ifndef LUDWIG_HIP_H
+#define LUDWIG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUDWIG_ABI_VERSION 1
+
+#define LUDWIG_OK              0
+#define LUDWIG_ERR_INVALID    -1   /* bad argument / inconsistent sizes          */
+#define LUDWIG_ERR_HIP        -2   /* a HIP runtime call failed                  */
+#define LUDWIG_ERR_NO_DEVICE  -3   /* no usable gfx950 device                    */
+#define LUDWIG_ERR_ALLOC      -4   /* device or host allocation failed           */
+#define LUDWIG_ERR_STATE      -5   /* call not valid for this level's storage    */
+
+/* Fields of BlockLevel (src/blocks.jl:16-65) addressable through upload/download/field_ptr. */
+enum LudwigField {
+    LUDWIG_F = 0,            /* f                 [8,8,8,nb,27] f32 */
+    LUDWIG_F_TEMP = 1,       /* f_temp            [8,8,8,nb,27] f32 */
+    LUDWIG_F_POST = 2,       /* f_post_collision  [8,8,8,nb,27] f32 (only if n_boundary_cells > 0) */
+    LUDWIG_F_OLD = 3,        /* f_old             [8,8,8,nb,27] f32 (only if temporal storage)     */
+    LUDWIG_RHO = 4,          /* rho               [8,8,8,nb]    f32 */
+    LUDWIG_RHO_OLD = 5,
+    LUDWIG_VEL = 6,          /* vel               [8,8,8,nb,3]  f32 */
+    LUDWIG_VEL_TEMP = 7,
+    LUDWIG_VEL_OLD = 8,
+    LUDWIG_OBSTACLE = 9,     /* obstacle          [8,8,8,nb]    u8 (Bool) */
+    LUDWIG_SPONGE = 10,      /* sponge            [8,8,8,nb]    f32 */
+    LUDWIG_WALL_DIST = 11,   /* wall_dist         [8,8,8,nb]    f32 */
+    LUDWIG_FIELD_COUNT = 12
+};
+
+/* Which blocks of a level a launch covers (multi-GPU overlap of halo exchange and interior work). */
+enum LudwigPart {
+    LUDWIG_PART_ALL = 0,
+    LUDWIG_PART_BOUNDARY = 1,   /* owned blocks flagged in LudwigLevelHost.comm_boundary */
+    LUDWIG_PART_INTERIOR = 2    /* the other owned blocks                                  */
+};
+
+typedef struct LudwigLevel LudwigLevel;   /* opaque; owns all device memory of one BlockLevel */
+
+/*
+ * Host description of one BlockLevel, consumed by ludwig_level_create, which replaces
+ * `adapt(backend, level)` (src/blocks.jl:67-87, called at src/main.jl:98).
+ * Optional pointers may be NULL: the constructor defaults of src/blocks.jl:118-150 apply
+ * (rho = 1, vel = 0, f = 0, obstacle = false, sponge = 0, wall_dist = 100).
+ */
+typedef struct LudwigLevelHost {
+    int32_t level_id;              /* 1-based, BlockLevel.level_id                                  */
+    int32_t n_blocks;              /* blocks in the arrays = owned blocks followed by ghost blocks  */
+    int32_t n_owned;               /* blocks this device steps; 0 means n_blocks (single device)    */
+    float   tau;                   /* BlockLevel.tau                                                */
+    int32_t grid_dim_x, grid_dim_y, grid_dim_z;   /* size(block_pointer)                            */
+    const int32_t *block_pointer;  /* [dim_x,dim_y,dim_z], 1-based, 0 = absent (src/blocks.jl:111-114) */
+    const int32_t *neighbor_table; /* [n_blocks,27], 1-based, 0 = absent (src/domain_topology.jl:135-160) */
+    const int32_t *map_x, *map_y, *map_z;         /* [n_blocks] 1-based block coords                */
+    const uint8_t *obstacle;       /* optional */
+    const float   *sponge;         /* optional */
+    const float   *wall_dist;      /* optional */
+    int32_t enable_temporal_interpolation;        /* allocate f_old/rho_old/vel_old (src/blocks.jl:123-142) */
+    int32_t n_boundary_cells;      /* > 0 with a q map enables Bouzidi (src/blocks.jl:152)          */
+    const uint16_t *bouzidi_q_map; /* Float16 bits [8,8,8,nb,27]; optional                          */
+    const int32_t  *bouzidi_cell_block;           /* [n_boundary_cells] 1-based                     */
+    const int8_t   *bouzidi_cell_x, *bouzidi_cell_y, *bouzidi_cell_z;   /* 1-based local coords     */
+    const uint8_t  *comm_boundary; /* optional [n_blocks]: 1 = owned block adjacent to a ghost block */
+} LudwigLevelHost;
+
+/*
+ * Scalar arguments of perform_timestep_v2! (src/physics_v2.jl:26-38) that are constant over a run,
+ * plus the globals it reads (SYMMETRIC_ANALYSIS src/physics_v2.jl:71, Q_MIN_THRESHOLD :93).
+ */
+typedef struct LudwigStepFlags {
+    int32_t domain_nx, domain_ny, domain_nz;   /* coarse (level-1) cell dims                 */
+    int32_t is_symmetric;
+    int32_t wall_model_active;
+    int32_t use_temporal_interp;
+    int32_t sponge_blend_distributions;
+    float   c_wale;
+    float   nu_sgs_background;
+    float   inlet_turbulence;
+    float   q_min_threshold;
+} LudwigStepFlags;
+
+/* ---- library ---- */
+int         ludwig_abi_version(void);
+const char *ludwig_last_error(void);
+int         ludwig_device_count(int *count);
+
+/* ---- level life cycle: adapt(backend, BlockLevel) src/blocks.jl:67-87 ---- */
+int  ludwig_level_create(const LudwigLevelHost *host, int device, LudwigLevel **out);
+void ludwig_level_destroy(LudwigLevel *level);
+
+/* HIP stream (hipStream_t) all later calls on this level are queued on; NULL = the null stream. */
+int  ludwig_level_set_stream(LudwigLevel *level, void *hip_stream);
+
+/*
+ * Launch order of the stream-collide workgroups. items[i] = (block0 << 3) | z0 with block0 0-based and
+ * z0 in {0,4}: one 256-thread workgroup steps z-planes z0..z0+3 of that block. Purely a performance
+ * knob (L2 / Infinity-Cache locality); results do not depend on it. Default: see DESIGN.md.
+ */
+int  ludwig_level_set_order(LudwigLevel *level, int part, const int32_t *items, int64_t n_items);
+
+/* Array(level.field) / copyto!(level.field, host) */
+int  ludwig_level_upload(LudwigLevel *level, int field, const void *host, size_t bytes);
+int  ludwig_level_download(const LudwigLevel *level, int field, void *host, size_t bytes);
+/* raw device pointer of a field (for halo buffers handed to RCCL by the host side) */
+int  ludwig_level_field_ptr(const LudwigLevel *level, int field, void **device_ptr, size_t *bytes);
+
+/* init_eq! (src/main.jl:109-134): f = f_temp = (f_old) = w_k, rho_old = 1, vel_old = 0 */
+int  ludwig_init_equilibrium(LudwigLevel *level);
+
+/* ---- stepping ---- */
+/*
+ * perform_timestep_v2! (src/physics_v2.jl:26-97) with the A/B roles of src/solver_control.jl:35-41
+ * derived from t_sub: iseven(t_sub) -> in = f/vel, out = f_temp/vel_temp, else swapped.
+ * parent == NULL <=> level 1 (parent_f === nothing). For a child, the parent's newest state is the
+ * output of the parent's step t_sub >> 1 (src/solver_control.jl:63-83) and is selected the same way.
+ * Runs stream-collide, then the Bouzidi correction if the level has boundary cells.
+ */
+int  ludwig_step(LudwigLevel *level, const LudwigLevel *parent, int64_t t_sub,
+                 float u_curr, float parent_tau, float temporal_weight,
+                 const LudwigStepFlags *flags);
+
+/* The two kernels of perform_timestep_v2! separately (src/physics_v2.jl:58-83 and :87-96), so that a
+ * multi-GPU caller can exchange halos in between and overlap interior work. `part` is a LudwigPart. */
+int  ludwig_stream_collide(LudwigLevel *level, const LudwigLevel *parent, int64_t t_sub,
+                           float u_curr, float parent_tau, float temporal_weight,
+                           const LudwigStepFlags *flags, int part);
+/* apply_bouzidi_correction! (src/bouzidi_kernel.jl:99-123) on the output buffer of step t_sub */
+int  ludwig_bouzidi_correction(LudwigLevel *level, int64_t t_sub, float q_min_threshold);
+
+/* copy_to_old!(level, f_in, vel_in) (src/blocks.jl:199-205) for the step t_sub about to run */
+int  ludwig_save_old(LudwigLevel *level, int64_t t_sub);
+
+/* KernelAbstractions.synchronize(backend) (src/solver_control.jl:164) */
+int  ludwig_sync(const LudwigLevel *level);
+
+/* ---- halo exchange helpers (no reference counterpart: the reference is single-device) ---- */
+/* dst[i] = field[index[i]] / field[index[i]] = src[i]; index, dst, src are DEVICE pointers,
+ * index holds element offsets into the field in the reference layout. */
+int  ludwig_halo_pack(const LudwigLevel *level, int field, const int64_t *index_dev, int64_t n,
+                      float *dst_dev);
+int  ludwig_halo_unpack(LudwigLevel *level, int field, const int64_t *index_dev, int64_t n,
+                        const float *src_dev);
+
+/* ---- introspection for benchmarks ---- */
+typedef struct LudwigLevelInfo {
+    int32_t n_blocks, n_owned;
+    int32_t n_fast_blocks;        /* blocks with all 26 neighbours present, no obstacle/sponge/wall work */
+    int32_t n_general_blocks;
+    int32_t n_boundary_cells;
+    int32_t has_temporal_storage, has_post_collision;
+    int64_t device_bytes;
+} LudwigLevelInfo;
+int  ludwig_level_info(const LudwigLevel *level, LudwigLevelInfo *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUDWIG_HIP_H */

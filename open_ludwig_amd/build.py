@@ -1,0 +1,44 @@
+"""Build libludwig_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["ludwig_hip.hip"]
+DEPENDS = ["ludwig_hip.hip", "kernels.hpp", "lattice.hpp", os.path.join("..", "..", "include", "ludwig_hip.h")]
+OUT = os.path.join(CSRC, "libludwig_hip.so")
+
+# -ffp-contract=off: the reference's CPU path never fuses a*b+c; parity with it is bit-level (DESIGN.md "Numerics").
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise FileNotFoundError("hipcc not found")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPENDS)
+
+
+def build_library(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc_path(), *HIPCC_FLAGS, *extra_flags, *SOURCES, "-o", OUT]
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(" ".join(cmd))
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed building libludwig_hip.so")
+    return OUT

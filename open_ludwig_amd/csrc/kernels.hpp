@@ -1,0 +1,547 @@
+// Device kernels of libludwig_hip.so (gfx950 / CDNA4 only).
+//
+// stream-collide  : reference src/physics_kernels.jl:9-358 (+ src/physics_utils.jl, src/physics_interpolation.jl)
+// bouzidi         : reference src/bouzidi_kernel.jl:13-92
+//
+// Arithmetic contract: every floating-point expression keeps the reference's operand order and is
+// compiled with -ffp-contract=off, so results are bit-identical to the scalar CPU restatement for
+// finite inputs. Multiplications by the lattice constants 0/+1/-1 are resolved at compile time
+// (x*1 = x, x*-1 = -x exactly; a dropped x*0 term only changes the sign of an exact zero).
+//
+// Mapping: one 64-lane wavefront = one 8x8 z-plane of one 8^3 block (lane = x + 8y), a 256-thread
+// workgroup = 4 consecutive z-planes. The block index and z are wave-uniform, so the 27 neighbour
+// block ids come through the scalar cache and each population load is one coalesced 256-B access
+// (plus the face/edge lanes that reach into a neighbour block).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "lattice.hpp"
+
+namespace lw {
+
+struct SCParams {
+    const float *f_in;
+    float *f_out;
+    float *f_post;            // nullptr unless store_post_collision
+    const float *vel_in;
+    float *vel_out;
+    float *rho;
+    const uint8_t *obstacle;
+    const float *sponge;
+    const float *wall_dist;
+    const int32_t *meta;      // [n_blocks][NBR_STRIDE]
+    const int32_t *items;     // work list: (block << 3) | z0
+    int64_t sk;               // population stride in elements = 512 * n_blocks
+    // parent level (coarse -> fine interface), unused on level 1
+    const float *pf_new, *pf_old, *prho_new, *prho_old, *pvel_new, *pvel_old;
+    const int32_t *pptr;      // parent block_pointer, 1-based, 0 = absent
+    int32_t pdim_x, pdim_y, pdim_z;
+    int64_t psk;
+    float tau, tau_parent, c_wale, nu_bg, u_inlet, inlet_turbulence, temporal_weight;
+    int32_t is_level_1, is_symmetric, nx_g, ny_g, nz_g;
+    int32_t wall_model, seed, use_temporal, sponge_blend;
+};
+
+template <int K, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        static_for<K + 1, N>(f);
+    }
+}
+
+// Julia's max() propagates NaN (reference uses Base.max throughout)
+__device__ __forceinline__ float jl_max(float a, float b)
+{
+    return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+__device__ __forceinline__ float jl_clamp(float x, float lo, float hi)
+{
+    return x > hi ? hi : (x < lo ? lo : x);
+}
+// Base.^(::Float32, ::Float32) and Base.log(::Float32) evaluate in Float64 and round once.
+__device__ __forceinline__ float jl_pow(float x, float y) { return (float)exp2(log2((double)x) * (double)y); }
+__device__ __forceinline__ float jl_log(float x) { return (float)log((double)x); }
+
+// c * v for c in {-1,0,1} resolved at compile time; `first` says whether the running sum is empty
+template <int C>
+__device__ __forceinline__ void acc_signed(float &sum, bool &empty, float v)
+{
+    if constexpr (C != 0) {
+        const float t = C > 0 ? v : -v;
+        sum = empty ? t : sum + t;
+        empty = false;
+    }
+}
+// cx*a + cy*b + cz*c, left-associated like the reference, zero terms dropped
+template <int K>
+__device__ __forceinline__ float cdot(float a, float b, float c)
+{
+    float s = 0.0f;
+    bool empty = true;
+    acc_signed<CX(K)>(s, empty, a);
+    acc_signed<CY(K)>(s, empty, b);
+    acc_signed<CZ(K)>(s, empty, c);
+    return s;
+}
+
+// reference src/physics_utils.jl:17-28 (Int32 products wrap)
+__device__ __forceinline__ float gradient_noise(int32_t gx, int32_t gy, int32_t gz, int32_t seed)
+{
+    uint32_t h = (uint32_t)gx * 374761393u + (uint32_t)gy * 668265263u + (uint32_t)gz * 1274126177u + (uint32_t)seed;
+    h = (h ^ (h >> 16)) * 0x85ebca6bu;
+    h = (h ^ (h >> 13)) * 0xc2b2ae35u;
+    h = h ^ (h >> 16);
+    return ((float)(h & 0xFFFFu) / 32768.0f) - 1.0f;
+}
+
+// reference src/physics_utils.jl:34-39
+__device__ __forceinline__ float calculate_equilibrium(float rho, float ux, float uy, float uz, float w_k,
+                                                       float cx, float cy, float cz)
+{
+    const float cu = cx * ux + cy * uy + cz * uz;
+    const float usq = ux * ux + uy * uy + uz * uz;
+    return rho * w_k * (1.0f + 3.0f * cu + 4.5f * cu * cu - 1.5f * usq);
+}
+
+// ---- coarse -> fine interface value, reference src/physics_interpolation.jl:16-138 ----
+struct Blend {
+    float f, rho, ux, uy, uz;
+    bool valid;
+};
+
+__device__ inline Blend get_blended(const SCParams &p, int pgx, int pgy, int pgz, int k, float w_k)
+{
+    const int pbx = (pgx - 1) / BS + 1, pby = (pgy - 1) / BS + 1, pbz = (pgz - 1) / BS + 1;
+    if (pbx >= 1 && pbx <= p.pdim_x && pby >= 1 && pby <= p.pdim_y && pbz >= 1 && pbz <= p.pdim_z) {
+        const int32_t pb = p.pptr[(int64_t)(pbx - 1) + (int64_t)p.pdim_x * ((int64_t)(pby - 1) + (int64_t)p.pdim_y * (pbz - 1))];
+        if (pb > 0) {
+            const int plx = (pgx - 1) % BS, ply = (pgy - 1) % BS, plz = (pgz - 1) % BS;   // 0-based
+            const int64_t c = (int64_t)plx + 8 * ply + 64 * plz + 512 * (int64_t)(pb - 1);
+            Blend r;
+            const float f_new = p.pf_new[c + p.psk * k];
+            const float rho_new = p.prho_new[c];
+            const float ux_new = p.pvel_new[c];
+            const float uy_new = p.pvel_new[c + p.psk];
+            const float uz_new = p.pvel_new[c + 2 * p.psk];
+            if (p.use_temporal == 1 && p.temporal_weight < 0.99f) {
+                const float tw = p.temporal_weight;
+                r.f = p.pf_old[c + p.psk * k] * (1.0f - tw) + f_new * tw;
+                r.rho = p.prho_old[c] * (1.0f - tw) + rho_new * tw;
+                r.ux = p.pvel_old[c] * (1.0f - tw) + ux_new * tw;
+                r.uy = p.pvel_old[c + p.psk] * (1.0f - tw) + uy_new * tw;
+                r.uz = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + uz_new * tw;
+                r.valid = true;
+                return r;
+            }
+            r.f = f_new; r.rho = rho_new; r.ux = ux_new; r.uy = uy_new; r.uz = uz_new; r.valid = true;
+            return r;
+        }
+    }
+    return Blend{w_k, 1.0f, 0.0f, 0.0f, 0.0f, false};
+}
+
+__device__ __forceinline__ float trilin(float v000, float v100, float v010, float v110, float v001, float v101,
+                                        float v011, float v111, float wx, float wy, float wz)
+{
+    const float c00 = v000 * (1.0f - wx) + v100 * wx;
+    const float c01 = v001 * (1.0f - wx) + v101 * wx;
+    const float c10 = v010 * (1.0f - wx) + v110 * wx;
+    const float c11 = v011 * (1.0f - wx) + v111 * wx;
+    const float c0 = c00 * (1.0f - wy) + c10 * wy;
+    const float c1 = c01 * (1.0f - wy) + c11 * wy;
+    return c0 * (1.0f - wz) + c1 * wz;
+}
+
+__device__ __noinline__ float interpolate_with_rescaling(const SCParams &p, int fine_gx, int fine_gy, int fine_gz, int k,
+                                                         float w_k, float cx, float cy, float cz)
+{
+    const float px_cont = ((float)fine_gx - 0.5f) * 0.5f;
+    const float py_cont = ((float)fine_gy - 0.5f) * 0.5f;
+    const float pz_cont = ((float)fine_gz - 0.5f) * 0.5f;
+    int px0 = (int)floorf(px_cont), py0 = (int)floorf(py_cont), pz0 = (int)floorf(pz_cont);
+    const int px1 = px0 + 1, py1 = py0 + 1, pz1 = pz0 + 1;   // before the clamp, as in the reference (:36-46)
+    const float wx = px_cont - (float)px0, wy = py_cont - (float)py0, wz = pz_cont - (float)pz0;
+    px0 = max(1, px0); py0 = max(1, py0); pz0 = max(1, pz0);
+
+    const Blend d000 = get_blended(p, px0, py0, pz0, k, w_k), d100 = get_blended(p, px1, py0, pz0, k, w_k);
+    const Blend d010 = get_blended(p, px0, py1, pz0, k, w_k), d110 = get_blended(p, px1, py1, pz0, k, w_k);
+    const Blend d001 = get_blended(p, px0, py0, pz1, k, w_k), d101 = get_blended(p, px1, py0, pz1, k, w_k);
+    const Blend d011 = get_blended(p, px0, py1, pz1, k, w_k), d111 = get_blended(p, px1, py1, pz1, k, w_k);
+    const Blend v000 = d000;
+    const Blend v100 = d100.valid ? d100 : v000, v010 = d010.valid ? d010 : v000, v110 = d110.valid ? d110 : v000;
+    const Blend v001 = d001.valid ? d001 : v000, v101 = d101.valid ? d101 : v000, v011 = d011.valid ? d011 : v000;
+    const Blend v111 = d111.valid ? d111 : v000;
+#define LW_TL(m) trilin(v000.m, v100.m, v010.m, v110.m, v001.m, v101.m, v011.m, v111.m, wx, wy, wz)
+    const float f_int = LW_TL(f), rho_int = LW_TL(rho), ux_int = LW_TL(ux), uy_int = LW_TL(uy), uz_int = LW_TL(uz);
+#undef LW_TL
+    const float feq_int = calculate_equilibrium(rho_int, ux_int, uy_int, uz_int, w_k, cx, cy, cz);
+    const float f_neq = f_int - feq_int;
+    const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
+    const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
+    return feq_int + f_neq * scale;
+}
+
+// ---- wall-model force, reference src/physics_kernels.jl:206-236 ----
+__device__ __noinline__ void wall_model_force(float dist_wall, float tau_molecular, float rho, float ux, float uy, float uz,
+                                              float &Fx, float &Fy, float &Fz)
+{
+    Fx = 0.0f; Fy = 0.0f; Fz = 0.0f;
+    if (dist_wall > 0.0f && dist_wall < 10.0f) {
+        const float u_mag = sqrtf(ux * ux + uy * uy + uz * uz);
+        const float nu_visc = (tau_molecular - 0.5f) / 3.0f;
+        if (u_mag > 1.0e-6f && nu_visc > 1.0e-10f) {
+            float u_tau = u_mag * jl_pow(nu_visc / (dist_wall * u_mag + 1.0e-10f), 1.0f / 7.0f) *
+                          jl_pow(2.0f * 8.3f, -1.0f / 7.0f);
+            u_tau = jl_max(u_tau, 1.0e-6f);
+            const float y_p = u_tau * dist_wall / nu_visc;
+            if (y_p > 11.81f) {
+                const float u_plus_law = (1.0f / KAPPA) * jl_log(y_p) + 5.2f;
+                if (u_plus_law > 0.1f) {
+                    u_tau = u_tau * ((u_mag / u_tau) / u_plus_law);
+                    u_tau = jl_max(u_tau, 1.0e-6f);
+                }
+            }
+            const float tau_wall = rho * u_tau * u_tau;
+            const float tau_res = rho * nu_visc * (u_mag / dist_wall);
+            if (tau_wall > tau_res) {
+                const float force_mag = (tau_wall - tau_res) / dist_wall;
+                Fx = -force_mag * ux / u_mag;
+                Fy = -force_mag * uy / u_mag;
+                Fz = -force_mag * uz / u_mag;
+            }
+        }
+    }
+}
+
+// previous-step velocity of the face neighbour (dx,dy,dz), reference src/physics_utils.jl:45-70
+template <int DX, int DY, int DZ, bool GENERAL>
+__device__ __forceinline__ void velocity_neighbor(const SCParams &p, const int32_t *meta, int b, int x, int y, int z,
+                                                  float &u1, float &u2, float &u3)
+{
+    const int nx = x + DX, ny = y + DY, nz = z + DZ;          // 0-based
+    const bool out = (DX != 0 && (nx < 0 || nx > 7)) || (DY != 0 && (ny < 0 || ny > 7)) || (DZ != 0 && (nz < 0 || nz > 7));
+    const int nb = meta[DIR(DX, DY, DZ)];                     // wave-uniform
+    int blk = out ? nb : b;
+    int cell = (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7);
+    if constexpr (GENERAL) {
+        if (blk < 0) { blk = b; cell = x + 8 * y + 64 * z; }  // missing neighbour block -> own value
+    }
+    const uint32_t off = (uint32_t)blk * CELLS + cell;
+    u1 = p.vel_in[off];
+    u2 = (p.vel_in + p.sk)[off];
+    u3 = (p.vel_in + 2 * p.sk)[off];
+}
+
+template <bool GENERAL>
+__global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
+{
+    const int item = p.items[blockIdx.x];
+    const int b = item >> 3;
+    const int z = (item & 7) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform z-plane, 0-based
+    const int lane = threadIdx.x & 63;
+    const int x = lane & 7, y = lane >> 3;
+    const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
+    const int flags = meta[NBR_FLAGS];
+    const int own_cell = x + 8 * y + 64 * z;
+    const uint32_t own = (uint32_t)b * CELLS + own_cell;
+
+    // ---- pull-stream, reference src/physics_kernels.jl:62-149 ----
+    float fs[Q];
+    float rho = 0.0f, jx = 0.0f, jy = 0.0f, jz = 0.0f;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+        const int sz = z - cz;                                   // wave-uniform
+        const int oz = sz < 0 ? -1 : (sz > 7 ? 1 : 0);
+        const bool xo = cx == 1 ? (x == 0) : (cx == -1 ? (x == 7) : false);
+        const bool yo = cy == 1 ? (y == 0) : (cy == -1 ? (y == 7) : false);
+        const int cell = ((x - cx) & 7) + 8 * ((y - cy) & 7) + 64 * (sz & 7);
+        // source block: own / x- / y- / xy-neighbour in z-layer oz (ids are wave-uniform scalars)
+        const int n00 = meta[DIR(0, 0, 0) + 9 * oz];
+        int sel = n00;
+        if constexpr (cx != 0 && cy != 0) {
+            const int nX = meta[DIR(-cx, 0, 0) + 9 * oz], nY = meta[DIR(0, -cy, 0) + 9 * oz], nXY = meta[DIR(-cx, -cy, 0) + 9 * oz];
+            sel = xo ? (yo ? nXY : nX) : (yo ? nY : n00);
+        } else if constexpr (cx != 0) {
+            const int nX = meta[DIR(-cx, 0, 0) + 9 * oz];
+            sel = xo ? nX : n00;
+        } else if constexpr (cy != 0) {
+            const int nY = meta[DIR(0, -cy, 0) + 9 * oz];
+            sel = yo ? nY : n00;
+        }
+        const float *__restrict__ fk = p.f_in + p.sk * k;
+        float val;
+        if constexpr (!GENERAL) {
+            val = fk[(uint32_t)sel * CELLS + cell];
+        } else {
+            if (sel >= 0) {
+                val = fk[(uint32_t)sel * CELLS + cell];
+            } else {
+                // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
+                const int gx = (meta[NBR_BX] - 1) * BS + x + 1, gy = (meta[NBR_BY] - 1) * BS + y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
+                const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
+                const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
+                const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
+                const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
+                if (is_inlet) {
+                    const float noise = p.inlet_turbulence > 0.0f
+                                            ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
+                                            : 0.0f;
+                    const float u_inst = p.u_inlet + noise;
+                    const float cu_in = (float)cx * u_inst;
+                    val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
+                } else if (is_outlet) {
+                    const float cu_out = (float)cx * p.u_inlet;
+                    val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
+                } else if (is_y_min && p.is_symmetric == 1) {
+                    val = (p.f_in + p.sk * MIRROR_Y(k))[own];
+                } else if (is_y_min || is_y_max) {
+                    val = (p.f_in + p.sk * MIRROR_Y(k))[own];
+                } else if (is_z_min || is_z_max) {
+                    val = (p.f_in + p.sk * MIRROR_Z(k))[own];
+                } else if (p.is_level_1 == 0) {
+                    val = interpolate_with_rescaling(p, src_gx, src_gy, src_gz, k, WEIGHT(k), (float)cx, (float)cy, (float)cz);
+                } else {
+                    val = WEIGHT(k);
+                }
+            }
+        }
+        fs[k] = val;
+        rho += val;
+        if constexpr (cx == 1) jx += val; else if constexpr (cx == -1) jx -= val;
+        if constexpr (cy == 1) jy += val; else if constexpr (cy == -1) jy -= val;
+        if constexpr (cz == 1) jz += val; else if constexpr (cz == -1) jz -= val;
+    });
+
+    float *__restrict__ f_out = p.f_out;
+    float *__restrict__ f_post = p.f_post;
+
+    // ---- obstacle cell: full-way bounce-back of the pulled set, reference :154-166 ----
+    bool is_obs = false;
+    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own] != 0;
+    if (is_obs) {
+        p.vel_out[own] = 0.0f;
+        (p.vel_out + p.sk)[own] = 0.0f;
+        (p.vel_out + 2 * p.sk)[own] = 0.0f;
+        p.rho[own] = 1.0f;
+        static_for<0, Q>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            const float f_coll = fs[OPP(k)];
+            (f_out + p.sk * k)[own] = f_coll;
+            if (f_post) (f_post + p.sk * k)[own] = f_coll;
+        });
+        return;
+    }
+
+    // ---- macroscopic moments, reference :172-176 ----
+    rho = jl_max(rho, 0.01f);
+    const float inv_rho = 1.0f / rho;
+    float ux = jx * inv_rho, uy = jy * inv_rho, uz = jz * inv_rho;
+
+    // ---- sponge, reference :181-199 ----
+    if (flags & FLAG_HAS_SPONGE) {
+        const float sp = p.sponge[own];
+        if (sp > 0.0f) {
+            const float rho_target = 1.0f, ux_target = p.u_inlet;
+            rho = rho * (1.0f - sp) + rho_target * sp;
+            ux = ux * (1.0f - sp) + ux_target * sp;
+            uy = uy * (1.0f - sp);
+            uz = uz * (1.0f - sp);
+            if (p.sponge_blend == 1) {
+                static_for<0, Q>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const float feq_target = calculate_equilibrium(rho_target, ux_target, 0.0f, 0.0f, WEIGHT(k),
+                                                                   (float)CX(k), (float)CY(k), (float)CZ(k));
+                    fs[k] = fs[k] * (1.0f - sp) + feq_target * sp;
+                });
+            }
+        }
+    }
+
+    // ---- wall-model force, reference :202-236 ----
+    float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
+    const bool wall_block = p.wall_model == 1 && (flags & FLAG_HAS_NEAR_WALL);   // wave-uniform
+    if (wall_block) wall_model_force(p.wall_dist[own], p.tau, rho, ux, uy, uz, Fx, Fy, Fz);
+
+    const float ux_eq = ux + 0.5f * Fx * inv_rho;
+    const float uy_eq = uy + 0.5f * Fy * inv_rho;
+    const float uz_eq = uz + 0.5f * Fz * inv_rho;
+    const float usq_eq = ux_eq * ux_eq + uy_eq * uy_eq + uz_eq * uz_eq;
+
+    p.vel_out[own] = ux;
+    (p.vel_out + p.sk)[own] = uy;
+    (p.vel_out + 2 * p.sk)[own] = uz;
+    p.rho[own] = rho;
+
+    // ---- WALE eddy viscosity from the previous step's velocity, reference :251-300 + physics_utils.jl:72-83 ----
+    float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
+    velocity_neighbor<1, 0, 0, GENERAL>(p, meta, b, x, y, z, ux_E, uy_E, uz_E);
+    velocity_neighbor<-1, 0, 0, GENERAL>(p, meta, b, x, y, z, ux_W, uy_W, uz_W);
+    velocity_neighbor<0, 1, 0, GENERAL>(p, meta, b, x, y, z, ux_N, uy_N, uz_N);
+    velocity_neighbor<0, -1, 0, GENERAL>(p, meta, b, x, y, z, ux_S, uy_S, uz_S);
+    velocity_neighbor<0, 0, 1, GENERAL>(p, meta, b, x, y, z, ux_T, uy_T, uz_T);
+    velocity_neighbor<0, 0, -1, GENERAL>(p, meta, b, x, y, z, ux_B, uy_B, uz_B);
+    const float g11 = 0.5f * (ux_E - ux_W), g12 = 0.5f * (ux_N - ux_S), g13 = 0.5f * (ux_T - ux_B);
+    const float g21 = 0.5f * (uy_E - uy_W), g22 = 0.5f * (uy_N - uy_S), g23 = 0.5f * (uy_T - uy_B);
+    const float g31 = 0.5f * (uz_E - uz_W), g32 = 0.5f * (uz_N - uz_S), g33 = 0.5f * (uz_T - uz_B);
+
+    const float gsq11 = g11 * g11 + g12 * g21 + g13 * g31;
+    const float gsq12 = g11 * g12 + g12 * g22 + g13 * g32;
+    const float gsq13 = g11 * g13 + g12 * g23 + g13 * g33;
+    const float gsq21 = g21 * g11 + g22 * g21 + g23 * g31;
+    const float gsq22 = g21 * g12 + g22 * g22 + g23 * g32;
+    const float gsq23 = g21 * g13 + g22 * g23 + g23 * g33;
+    const float gsq31 = g31 * g11 + g32 * g21 + g33 * g31;
+    const float gsq32 = g31 * g12 + g32 * g22 + g33 * g32;
+    const float gsq33 = g31 * g13 + g32 * g23 + g33 * g33;
+
+    const float tr_gsq = gsq11 + gsq22 + gsq33;
+    const float tr_term = tr_gsq / 3.0f;
+    const float Sd11 = gsq11 - tr_term, Sd22 = gsq22 - tr_term, Sd33 = gsq33 - tr_term;
+    const float Sd12 = 0.5f * (gsq12 + gsq21), Sd13 = 0.5f * (gsq13 + gsq31), Sd23 = 0.5f * (gsq23 + gsq32);
+    const float S12 = 0.5f * (g12 + g21), S13 = 0.5f * (g13 + g31), S23 = 0.5f * (g23 + g32);
+    const float OP1 = Sd11 * Sd11 + Sd22 * Sd22 + Sd33 * Sd33 + 2.0f * (Sd12 * Sd12 + Sd13 * Sd13 + Sd23 * Sd23);
+    const float OP2 = g11 * g11 + g22 * g22 + g33 * g33 + 2.0f * (S12 * S12 + S13 * S13 + S23 * S23);
+
+    float nu_eddy = 0.0f;
+    if (OP1 > 1.0e-12f) {
+        const float OP1_32 = OP1 * sqrtf(OP1);
+        const float OP2_52 = OP2 * OP2 * sqrtf(jl_max(OP2, 1.0e-12f));
+        const float denom = OP2_52 + OP1 * sqrtf(sqrtf(jl_max(OP1, 1.0e-12f)));
+        if (denom > 1.0e-12f) nu_eddy = (p.c_wale * p.c_wale) * OP1_32 / denom;
+    }
+    nu_eddy = jl_max(nu_eddy, p.nu_bg);
+    const float tau_turb = p.tau + nu_eddy * 3.0f;
+    const float omega = 1.0f / jl_max(tau_turb, 0.500001f);
+
+    // ---- non-equilibrium stress, reference :305-322 ----
+    float Pi_xx = 0.0f, Pi_yy = 0.0f, Pi_zz = 0.0f, Pi_xy = 0.0f, Pi_yz = 0.0f, Pi_zx = 0.0f;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+        const float cu = cdot<k>(ux_eq, uy_eq, uz_eq);
+        const float feq = rho * WEIGHT(k) * (1.0f + 3.0f * cu + 4.5f * cu * cu - 1.5f * usq_eq);
+        const float f_neq = fs[k] - feq;
+        if constexpr (cx != 0) Pi_xx += f_neq;
+        if constexpr (cy != 0) Pi_yy += f_neq;
+        if constexpr (cz != 0) Pi_zz += f_neq;
+        if constexpr (cx * cy == 1) Pi_xy += f_neq; else if constexpr (cx * cy == -1) Pi_xy -= f_neq;
+        if constexpr (cy * cz == 1) Pi_yz += f_neq; else if constexpr (cy * cz == -1) Pi_yz -= f_neq;
+        if constexpr (cz * cx == 1) Pi_zx += f_neq; else if constexpr (cz * cx == -1) Pi_zx -= f_neq;
+    });
+
+    // ---- regularized collision + write, reference :324-354 ----
+    const float one_m_omega = 1.0f - omega;
+    const float one_m_half_omega = 1.0f - 0.5f * omega;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+        constexpr float w_k = WEIGHT(k);
+        constexpr float cx_f = (float)cx, cy_f = (float)cy, cz_f = (float)cz;
+        const float cu = cdot<k>(ux_eq, uy_eq, uz_eq);
+        const float feq = rho * w_k * (1.0f + 3.0f * cu + 4.5f * cu * cu - 1.5f * usq_eq);
+        constexpr float Q_xx = cx_f * cx_f - CS2_PHYSICS, Q_yy = cy_f * cy_f - CS2_PHYSICS, Q_zz = cz_f * cz_f - CS2_PHYSICS;
+        // Pi_xy*cx*cy + Pi_yz*cy*cz + Pi_zx*cz*cx, left-associated, zero terms dropped
+        float od = 0.0f;
+        bool od_empty = true;
+        acc_signed<cx * cy>(od, od_empty, Pi_xy);
+        acc_signed<cy * cz>(od, od_empty, Pi_yz);
+        acc_signed<cz * cx>(od, od_empty, Pi_zx);
+        const float f_neq_reg = (w_k * 4.5f) * (Pi_xx * Q_xx + Pi_yy * Q_yy + Pi_zz * Q_zz + 2.0f * od);
+        float f_coll;
+        if (wall_block) {
+            const float force_term = (w_k * 3.0f) * ((cx_f - ux + 3.0f * cu * cx_f) * Fx + (cy_f - uy + 3.0f * cu * cy_f) * Fy +
+                                                     (cz_f - uz + 3.0f * cu * cz_f) * Fz);
+            f_coll = feq + one_m_omega * f_neq_reg + one_m_half_omega * force_term;
+        } else {
+            f_coll = feq + one_m_omega * f_neq_reg;   // force_term is an exact zero
+        }
+        if (f_post) (f_post + p.sk * k)[own] = f_coll;
+        (f_out + p.sk * k)[own] = f_coll;
+    });
+}
+
+// ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----
+struct BouzidiParams {
+    float *f_out;
+    const float *f_post;
+    const _Float16 *q_map;
+    const int32_t *cell_block;   // 0-based
+    const int8_t *cell_x, *cell_y, *cell_z;   // 0-based
+    const int32_t *meta;
+    int64_t sk;
+    int32_t n_cells;
+    float q_min;
+};
+
+__global__ __launch_bounds__(64) void k_bouzidi(const BouzidiParams p)
+{
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= p.n_cells) return;
+    const int b = p.cell_block[c];
+    const int x = p.cell_x[c], y = p.cell_y[c], z = p.cell_z[c];
+    const int64_t own = (int64_t)b * CELLS + x + 8 * y + 64 * z;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int opp_k = OPP(k);
+        const float q = (float)p.q_map[own + p.sk * k];
+        if (q > p.q_min && q <= 1.0f) {
+            const float f_k = p.f_post[own + p.sk * k];
+            if (q < 0.5f) {
+                const int nx = x + CX(opp_k), ny = y + CY(opp_k), nz = z + CZ(opp_k);
+                float f_ff = f_k;
+                if (nx >= 0 && nx < BS && ny >= 0 && ny < BS && nz >= 0 && nz < BS) {
+                    f_ff = p.f_post[(int64_t)b * CELLS + nx + 8 * ny + 64 * nz + p.sk * k];
+                } else {
+                    const int ox = nx < 0 ? -1 : (nx >= BS ? 1 : 0);
+                    const int oy = ny < 0 ? -1 : (ny >= BS ? 1 : 0);
+                    const int oz = nz < 0 ? -1 : (nz >= BS ? 1 : 0);
+                    const int nbb = p.meta[(int64_t)b * NBR_STRIDE + DIR(ox, oy, oz)];
+                    if (nbb >= 0) f_ff = p.f_post[(int64_t)nbb * CELLS + (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7) + p.sk * k];
+                }
+                const float coeff1 = 2.0f * q;
+                p.f_out[own + p.sk * opp_k] = coeff1 * f_k + (1.0f - coeff1) * f_ff;
+            } else {
+                const float f_opp_post = p.f_post[own + p.sk * opp_k];
+                const float inv_2q = 1.0f / (2.0f * q);
+                const float coeff2 = (2.0f * q - 1.0f) * inv_2q;
+                p.f_out[own + p.sk * opp_k] = inv_2q * f_k + coeff2 * f_opp_post;
+            }
+        }
+    });
+}
+
+// ---- init_eq!, reference src/main.jl:109-124 ----
+__global__ void k_fill_weights(float *f, int64_t sk)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sk) return;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        f[i + sk * k] = WEIGHT(k);
+    });
+}
+__global__ void k_fill(float *a, int64_t n, float v)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = v;
+}
+
+// ---- halo pack / unpack ----
+__global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = field[index[i]];
+}
+__global__ void k_scatter(float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, const float *__restrict__ src)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) field[index[i]] = src[i];
+}
+
+}  // namespace lw

@@ -1,0 +1,600 @@
+// libludwig_hip.so - C ABI (include/ludwig_hip.h) over the gfx950 kernels in kernels.hpp.
+// Host side only: memory ownership, block classification, work lists, launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ludwig_hip.h"
+#include "kernels.hpp"
+
+using namespace lw;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define LW_HIP(call)                                                                                      \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return fail(LUDWIG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int N_PARTS = 3, N_CLASSES = 2;   // class 0 = all-neighbours-present kernel, 1 = general kernel
+
+}  // namespace
+
+struct LudwigLevel {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int level_id = 1, n_blocks = 0, n_owned = 0;
+    float tau = 1.0f;
+    int gdx = 0, gdy = 0, gdz = 0;
+    int64_t sk = 0;   // 512 * n_blocks
+    float *f[2] = {nullptr, nullptr};      // f, f_temp
+    float *vel[2] = {nullptr, nullptr};    // vel, vel_temp
+    float *rho = nullptr, *f_post = nullptr, *f_old = nullptr, *rho_old = nullptr, *vel_old = nullptr;
+    uint8_t *obstacle = nullptr;
+    float *sponge = nullptr, *wall_dist = nullptr;
+    int32_t *meta = nullptr, *block_pointer = nullptr;
+    bool has_temporal = false, has_post = false, bouzidi_enabled = false;
+    int n_bc = 0;
+    _Float16 *q_map = nullptr;
+    int32_t *cell_block = nullptr;
+    int8_t *cell_x = nullptr, *cell_y = nullptr, *cell_z = nullptr;
+    std::vector<int32_t> h_meta;
+    std::vector<uint8_t> h_comm_boundary;
+    int32_t *items[N_PARTS][N_CLASSES] = {};
+    int64_t n_items[N_PARTS][N_CLASSES] = {};
+    int n_fast_blocks = 0;
+    int64_t device_bytes = 0;
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(LudwigLevel *L, T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) return LUDWIG_OK;
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) return fail(LUDWIG_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    L->device_bytes += (int64_t)(count * sizeof(T));
+    return LUDWIG_OK;
+}
+
+int fill(LudwigLevel *L, float *a, int64_t n, float v)
+{
+    if (n == 0) return LUDWIG_OK;
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L->stream, a, n, v);
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+struct FieldDesc {
+    void *ptr;
+    size_t bytes;
+};
+
+FieldDesc field_desc(const LudwigLevel *L, int field)
+{
+    const size_t c = (size_t)L->sk;
+    switch (field) {
+    case LUDWIG_F: return {L->f[0], c * Q * 4};
+    case LUDWIG_F_TEMP: return {L->f[1], c * Q * 4};
+    case LUDWIG_F_POST: return {L->f_post, L->has_post ? c * Q * 4 : 0};
+    case LUDWIG_F_OLD: return {L->f_old, L->has_temporal ? c * Q * 4 : 0};
+    case LUDWIG_RHO: return {L->rho, c * 4};
+    case LUDWIG_RHO_OLD: return {L->rho_old, L->has_temporal ? c * 4 : 0};
+    case LUDWIG_VEL: return {L->vel[0], c * 3 * 4};
+    case LUDWIG_VEL_TEMP: return {L->vel[1], c * 3 * 4};
+    case LUDWIG_VEL_OLD: return {L->vel_old, L->has_temporal ? c * 3 * 4 : 0};
+    case LUDWIG_OBSTACLE: return {L->obstacle, c};
+    case LUDWIG_SPONGE: return {L->sponge, c * 4};
+    case LUDWIG_WALL_DIST: return {L->wall_dist, c * 4};
+    default: return {nullptr, 0};
+    }
+}
+
+// per-block flags that let the kernel skip loads: recomputed whenever the host hands us the field
+void scan_flags(LudwigLevel *L, int field, const void *host)
+{
+    const int flag = field == LUDWIG_OBSTACLE ? FLAG_HAS_OBSTACLE : field == LUDWIG_SPONGE ? FLAG_HAS_SPONGE : FLAG_HAS_NEAR_WALL;
+    for (int b = 0; b < L->n_blocks; ++b) {
+        bool any = false;
+        if (host) {
+            if (field == LUDWIG_OBSTACLE) {
+                const uint8_t *o = (const uint8_t *)host + (size_t)b * CELLS;
+                for (int i = 0; i < CELLS && !any; ++i) any = o[i] != 0;
+            } else if (field == LUDWIG_SPONGE) {
+                const float *s = (const float *)host + (size_t)b * CELLS;
+                for (int i = 0; i < CELLS && !any; ++i) any = s[i] > 0.0f;
+            } else {
+                const float *d = (const float *)host + (size_t)b * CELLS;
+                for (int i = 0; i < CELLS && !any; ++i) any = d[i] > 0.0f && d[i] < 10.0f;
+            }
+        }
+        int32_t &fl = L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS];
+        fl = any ? (fl | flag) : (fl & ~flag);
+    }
+}
+
+int upload_meta(LudwigLevel *L)
+{
+    if (L->n_blocks == 0) return LUDWIG_OK;
+    LW_HIP(hipMemcpyAsync(L->meta, L->h_meta.data(), L->h_meta.size() * 4, hipMemcpyHostToDevice, L->stream));
+    LW_HIP(hipStreamSynchronize(L->stream));
+    return LUDWIG_OK;
+}
+
+bool block_in_part(const LudwigLevel *L, int b, int part)
+{
+    if (b >= L->n_owned) return false;
+    if (part == LUDWIG_PART_ALL) return true;
+    const bool bnd = !L->h_comm_boundary.empty() && L->h_comm_boundary[b] != 0;
+    return part == LUDWIG_PART_BOUNDARY ? bnd : !bnd;
+}
+
+int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
+{
+    std::vector<int32_t> cls[N_CLASSES];
+    for (int64_t i = 0; i < n; ++i) {
+        const int b = items[i] >> 3, z0 = items[i] & 7;
+        if (b < 0 || b >= L->n_owned || (z0 != 0 && z0 != 4)) return fail(LUDWIG_ERR_INVALID, "work item %lld = (block %d, z0 %d) is not valid", (long long)i, b, z0);
+        if (!block_in_part(L, b, part)) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not in part %d", (long long)i, b, part);
+        const bool fast = (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0;
+        cls[fast ? 0 : 1].push_back(items[i]);
+    }
+    for (int c = 0; c < N_CLASSES; ++c) {
+        if (L->items[part][c]) { (void)hipFree(L->items[part][c]); L->items[part][c] = nullptr; }
+        L->n_items[part][c] = (int64_t)cls[c].size();
+        if (!cls[c].empty()) {
+            LW_HIP(hipMalloc((void **)&L->items[part][c], cls[c].size() * 4));
+            LW_HIP(hipMemcpy(L->items[part][c], cls[c].data(), cls[c].size() * 4, hipMemcpyHostToDevice));
+        }
+    }
+    return LUDWIG_OK;
+}
+
+// Default launch order. Workgroups are dealt round-robin to the 8 XCDs (each with a private L2), so
+// workgroup g runs on XCD g % 8. We hand every XCD a contiguous run of the block list: blocks that are
+// adjacent in the list (z-neighbours in the reference's sort order, bz fastest) then share an L2 while
+// the lines of their common face are hot.
+int default_items(LudwigLevel *L, int part)
+{
+    std::vector<int32_t> seq;
+    for (int b = 0; b < L->n_owned; ++b)
+        if (block_in_part(L, b, part)) { seq.push_back(b << 3); seq.push_back((b << 3) | 4); }
+    // the fast / general split happens in set_items and keeps relative order; interleave per class there
+    return set_items(L, part, seq.data(), (int64_t)seq.size());
+}
+
+int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float u_curr, float parent_tau,
+                          float temporal_weight, const LudwigStepFlags *fl, int part)
+{
+    if (!L || !fl) return fail(LUDWIG_ERR_INVALID, "null level or flags");
+    if (part < 0 || part >= N_PARTS) return fail(LUDWIG_ERR_INVALID, "bad part %d", part);
+    if (t_sub < 0) return fail(LUDWIG_ERR_INVALID, "t_sub must be >= 0");
+    if (L->n_blocks == 0) return LUDWIG_OK;   // reference src/physics_v2.jl:41
+    if (parent && parent->device != L->device) return fail(LUDWIG_ERR_INVALID, "parent level lives on another device");
+    LW_HIP(hipSetDevice(L->device));
+    const int in = (t_sub % 2 == 0) ? 0 : 1, out = 1 - in;   // reference src/solver_control.jl:35-41
+    SCParams p{};
+    p.f_in = L->f[in];
+    p.f_out = L->f[out];
+    p.vel_in = L->vel[in];
+    p.vel_out = L->vel[out];
+    p.rho = L->rho;
+    p.f_post = (L->bouzidi_enabled && L->n_bc > 0) ? L->f_post : nullptr;   // reference src/physics_v2.jl:77
+    p.obstacle = L->obstacle;
+    p.sponge = L->sponge;
+    p.wall_dist = L->wall_dist;
+    p.meta = L->meta;
+    p.sk = L->sk;
+    if (parent) {
+        const int pout = ((t_sub >> 1) % 2 == 0) ? 1 : 0;   // output buffer of the parent's step t_sub >> 1
+        p.pf_new = parent->f[pout];
+        p.pvel_new = parent->vel[pout];
+        p.prho_new = parent->rho;
+        // without temporal storage the reference passes 1-element dummies that are never read
+        // (use_temporal_interp is then false at every call site that matters); alias "new" to stay in bounds
+        p.pf_old = parent->has_temporal ? parent->f_old : parent->f[pout];
+        p.prho_old = parent->has_temporal ? parent->rho_old : parent->rho;
+        p.pvel_old = parent->has_temporal ? parent->vel_old : parent->vel[pout];
+        p.pptr = parent->block_pointer;
+        p.pdim_x = parent->gdx; p.pdim_y = parent->gdy; p.pdim_z = parent->gdz;
+        p.psk = parent->sk;
+        p.is_level_1 = 0;
+    } else {
+        p.is_level_1 = 1;
+    }
+    p.tau = L->tau;
+    p.tau_parent = parent_tau;
+    p.c_wale = fl->c_wale;
+    p.nu_bg = fl->nu_sgs_background;
+    p.u_inlet = u_curr;
+    p.inlet_turbulence = fl->inlet_turbulence;
+    p.temporal_weight = temporal_weight;
+    p.is_symmetric = fl->is_symmetric ? 1 : 0;
+    const int scale = 1 << (L->level_id - 1);   // reference src/physics_v2.jl:55-56
+    p.nx_g = fl->domain_nx * scale; p.ny_g = fl->domain_ny * scale; p.nz_g = fl->domain_nz * scale;
+    p.wall_model = fl->wall_model_active ? 1 : 0;
+    p.seed = (int32_t)(t_sub % 1000000);        // reference src/physics_v2.jl:76
+    // a parent without temporal storage cannot be blended with (reference would index a dummy array)
+    p.use_temporal = (fl->use_temporal_interp && (!parent || parent->has_temporal)) ? 1 : 0;
+    p.sponge_blend = fl->sponge_blend_distributions ? 1 : 0;
+
+    if (L->n_items[part][0] > 0) {
+        p.items = L->items[part][0];
+        hipLaunchKernelGGL(k_stream_collide<false>, dim3((unsigned)L->n_items[part][0]), dim3(256), 0, L->stream, p);
+        LW_HIP(hipGetLastError());
+    }
+    if (L->n_items[part][1] > 0) {
+        p.items = L->items[part][1];
+        hipLaunchKernelGGL(k_stream_collide<true>, dim3((unsigned)L->n_items[part][1]), dim3(256), 0, L->stream, p);
+        LW_HIP(hipGetLastError());
+    }
+    return LUDWIG_OK;
+}
+
+int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
+{
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    if (!(L->bouzidi_enabled && L->n_bc > 0)) return LUDWIG_OK;   // reference src/bouzidi_kernel.jl:107-109
+    LW_HIP(hipSetDevice(L->device));
+    const int out = (t_sub % 2 == 0) ? 1 : 0;
+    BouzidiParams p{};
+    p.f_out = L->f[out];
+    p.f_post = L->f_post;
+    p.q_map = L->q_map;
+    p.cell_block = L->cell_block;
+    p.cell_x = L->cell_x; p.cell_y = L->cell_y; p.cell_z = L->cell_z;
+    p.meta = L->meta;
+    p.sk = L->sk;
+    p.n_cells = L->n_bc;
+    p.q_min = q_min;
+    hipLaunchKernelGGL(k_bouzidi, dim3((unsigned)((L->n_bc + 63) / 64)), dim3(64), 0, L->stream, p);
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ludwig_abi_version(void) { return LUDWIG_ABI_VERSION; }
+
+const char *ludwig_last_error(void) { return g_err.c_str(); }
+
+int ludwig_device_count(int *count)
+{
+    if (!count) return fail(LUDWIG_ERR_INVALID, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(LUDWIG_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return LUDWIG_OK;
+}
+
+void ludwig_level_destroy(LudwigLevel *L)
+{
+    if (!L) return;
+    (void)hipSetDevice(L->device);
+    void *ptrs[] = {L->f[0], L->f[1], L->vel[0], L->vel[1], L->rho, L->f_post, L->f_old, L->rho_old, L->vel_old, L->obstacle,
+                    L->sponge, L->wall_dist, L->meta, L->block_pointer, L->q_map, L->cell_block, L->cell_x, L->cell_y, L->cell_z};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (int a = 0; a < N_PARTS; ++a)
+        for (int c = 0; c < N_CLASSES; ++c)
+            if (L->items[a][c]) (void)hipFree(L->items[a][c]);
+    delete L;
+}
+
+int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
+{
+    if (!h || !out) return fail(LUDWIG_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (h->n_blocks < 0 || h->level_id < 1 || h->level_id > 30) return fail(LUDWIG_ERR_INVALID, "bad n_blocks/level_id");
+    if (h->n_blocks > 0 && (!h->neighbor_table || !h->map_x || !h->map_y || !h->map_z)) return fail(LUDWIG_ERR_INVALID, "neighbor_table and map_x/y/z are required");
+    if ((int64_t)h->n_blocks * CELLS >= (int64_t)1 << 31) return fail(LUDWIG_ERR_INVALID, "n_blocks too large for 32-bit cell offsets");
+    const int n_owned = h->n_owned > 0 ? h->n_owned : h->n_blocks;
+    if (n_owned > h->n_blocks) return fail(LUDWIG_ERR_INVALID, "n_owned > n_blocks");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LUDWIG_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(LUDWIG_ERR_INVALID, "device %d out of range (have %d)", device, ndev);
+    LW_HIP(hipSetDevice(device));
+
+    LudwigLevel *L = new (std::nothrow) LudwigLevel();
+    if (!L) return fail(LUDWIG_ERR_ALLOC, "host allocation failed");
+    L->device = device;
+    L->level_id = h->level_id;
+    L->n_blocks = h->n_blocks;
+    L->n_owned = n_owned;
+    L->tau = h->tau;
+    L->gdx = h->grid_dim_x; L->gdy = h->grid_dim_y; L->gdz = h->grid_dim_z;
+    L->sk = (int64_t)h->n_blocks * CELLS;
+    const size_t c = (size_t)L->sk, nb = (size_t)h->n_blocks;
+    L->has_temporal = h->enable_temporal_interpolation && nb > 0;            // reference src/blocks.jl:123
+    L->bouzidi_enabled = h->n_boundary_cells > 0 && h->bouzidi_q_map;        // reference src/blocks.jl:152
+    L->n_bc = L->bouzidi_enabled ? h->n_boundary_cells : 0;
+    L->has_post = h->n_boundary_cells > 0 && nb > 0;                          // reference src/blocks.jl:135
+    if (L->bouzidi_enabled && (!h->bouzidi_cell_block || !h->bouzidi_cell_x || !h->bouzidi_cell_y || !h->bouzidi_cell_z)) {
+        delete L;
+        return fail(LUDWIG_ERR_INVALID, "bouzidi cell lists missing");
+    }
+
+    int rc = LUDWIG_OK;
+#define LW_TRY(expr) do { if (rc == LUDWIG_OK) rc = (expr); } while (0)
+    LW_TRY(dev_alloc(L, &L->f[0], c * Q));
+    LW_TRY(dev_alloc(L, &L->f[1], c * Q));
+    LW_TRY(dev_alloc(L, &L->vel[0], c * 3));
+    LW_TRY(dev_alloc(L, &L->vel[1], c * 3));
+    LW_TRY(dev_alloc(L, &L->rho, c));
+    if (L->has_post) LW_TRY(dev_alloc(L, &L->f_post, c * Q));
+    if (L->has_temporal) {
+        LW_TRY(dev_alloc(L, &L->f_old, c * Q));
+        LW_TRY(dev_alloc(L, &L->rho_old, c));
+        LW_TRY(dev_alloc(L, &L->vel_old, c * 3));
+    }
+    LW_TRY(dev_alloc(L, &L->obstacle, c));
+    LW_TRY(dev_alloc(L, &L->sponge, c));
+    LW_TRY(dev_alloc(L, &L->wall_dist, c));
+    LW_TRY(dev_alloc(L, &L->meta, nb * NBR_STRIDE));
+    const size_t nptr = (size_t)h->grid_dim_x * h->grid_dim_y * h->grid_dim_z;
+    if (h->block_pointer && nptr > 0) LW_TRY(dev_alloc(L, &L->block_pointer, nptr));
+    if (L->bouzidi_enabled) {
+        LW_TRY(dev_alloc(L, &L->q_map, c * Q));
+        LW_TRY(dev_alloc(L, &L->cell_block, (size_t)L->n_bc));
+        LW_TRY(dev_alloc(L, &L->cell_x, (size_t)L->n_bc));
+        LW_TRY(dev_alloc(L, &L->cell_y, (size_t)L->n_bc));
+        LW_TRY(dev_alloc(L, &L->cell_z, (size_t)L->n_bc));
+    }
+    if (rc != LUDWIG_OK) { ludwig_level_destroy(L); return rc; }
+
+    // metadata rows: neighbours 0-based (-1 absent), flags, block coords
+    L->h_meta.assign(nb * NBR_STRIDE, 0);
+    for (size_t b = 0; b < nb; ++b) {
+        int32_t *row = &L->h_meta[b * NBR_STRIDE];
+        bool all = true;
+        for (int d = 0; d < 27; ++d) {
+            const int32_t v = h->neighbor_table[b + nb * d];
+            if (v < 0 || v > h->n_blocks) { ludwig_level_destroy(L); return fail(LUDWIG_ERR_INVALID, "neighbor_table[%zu,%d] = %d out of range", b + 1, d + 1, v); }
+            row[d] = v - 1;
+            if (d != 13 && v == 0) all = false;
+        }
+        row[13] = (int32_t)b;   // the block itself; the reference never reads this entry
+        row[NBR_FLAGS] = all ? FLAG_ALL_NEIGHBOURS : 0;
+        row[NBR_BX] = h->map_x[b]; row[NBR_BY] = h->map_y[b]; row[NBR_BZ] = h->map_z[b];
+    }
+    if (h->comm_boundary) L->h_comm_boundary.assign(h->comm_boundary, h->comm_boundary + nb);
+    scan_flags(L, LUDWIG_OBSTACLE, h->obstacle);
+    scan_flags(L, LUDWIG_SPONGE, h->sponge);
+    scan_flags(L, LUDWIG_WALL_DIST, h->wall_dist);
+    for (int b = 0; b < n_owned; ++b)
+        if (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) ++L->n_fast_blocks;
+
+    auto init = [&]() -> int {
+        // constructor defaults, reference src/blocks.jl:118-150
+        LW_HIP(hipMemsetAsync(L->f[0], 0, c * Q * 4, L->stream));
+        LW_HIP(hipMemsetAsync(L->f[1], 0, c * Q * 4, L->stream));
+        LW_HIP(hipMemsetAsync(L->vel[0], 0, c * 3 * 4, L->stream));
+        LW_HIP(hipMemsetAsync(L->vel[1], 0, c * 3 * 4, L->stream));
+        int r = fill(L, L->rho, L->sk, 1.0f);
+        if (r) return r;
+        if (L->has_post) LW_HIP(hipMemsetAsync(L->f_post, 0, c * Q * 4, L->stream));
+        if (L->has_temporal) {
+            LW_HIP(hipMemsetAsync(L->f_old, 0, c * Q * 4, L->stream));
+            LW_HIP(hipMemsetAsync(L->vel_old, 0, c * 3 * 4, L->stream));
+            if ((r = fill(L, L->rho_old, L->sk, 1.0f))) return r;
+        }
+        if (h->obstacle) LW_HIP(hipMemcpyAsync(L->obstacle, h->obstacle, c, hipMemcpyHostToDevice, L->stream));
+        else LW_HIP(hipMemsetAsync(L->obstacle, 0, c, L->stream));
+        if (h->sponge) LW_HIP(hipMemcpyAsync(L->sponge, h->sponge, c * 4, hipMemcpyHostToDevice, L->stream));
+        else LW_HIP(hipMemsetAsync(L->sponge, 0, c * 4, L->stream));
+        if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, c * 4, hipMemcpyHostToDevice, L->stream));
+        else if ((r = fill(L, L->wall_dist, L->sk, 100.0f))) return r;
+        if (L->block_pointer) LW_HIP(hipMemcpyAsync(L->block_pointer, h->block_pointer, nptr * 4, hipMemcpyHostToDevice, L->stream));
+        if (L->bouzidi_enabled) {
+            LW_HIP(hipMemcpyAsync(L->q_map, h->bouzidi_q_map, c * Q * 2, hipMemcpyHostToDevice, L->stream));
+            std::vector<int32_t> cb((size_t)L->n_bc);
+            std::vector<int8_t> cx((size_t)L->n_bc), cy((size_t)L->n_bc), cz((size_t)L->n_bc);
+            for (int i = 0; i < L->n_bc; ++i) {
+                cb[i] = h->bouzidi_cell_block[i] - 1;
+                cx[i] = (int8_t)(h->bouzidi_cell_x[i] - 1); cy[i] = (int8_t)(h->bouzidi_cell_y[i] - 1); cz[i] = (int8_t)(h->bouzidi_cell_z[i] - 1);
+                if (cb[i] < 0 || cb[i] >= L->n_blocks || cx[i] < 0 || cx[i] > 7 || cy[i] < 0 || cy[i] > 7 || cz[i] < 0 || cz[i] > 7)
+                    return fail(LUDWIG_ERR_INVALID, "bouzidi cell %d out of range", i + 1);
+            }
+            LW_HIP(hipMemcpy(L->cell_block, cb.data(), cb.size() * 4, hipMemcpyHostToDevice));
+            LW_HIP(hipMemcpy(L->cell_x, cx.data(), cx.size(), hipMemcpyHostToDevice));
+            LW_HIP(hipMemcpy(L->cell_y, cy.data(), cy.size(), hipMemcpyHostToDevice));
+            LW_HIP(hipMemcpy(L->cell_z, cz.data(), cz.size(), hipMemcpyHostToDevice));
+        }
+        LW_HIP(hipStreamSynchronize(L->stream));
+        int r2 = upload_meta(L);
+        if (r2) return r2;
+        for (int part = 0; part < N_PARTS; ++part)
+            if ((r2 = default_items(L, part))) return r2;
+        return LUDWIG_OK;
+    };
+    rc = nb > 0 ? init() : LUDWIG_OK;
+    if (rc != LUDWIG_OK) { ludwig_level_destroy(L); return rc; }
+#undef LW_TRY
+    *out = L;
+    return LUDWIG_OK;
+}
+
+int ludwig_level_set_stream(LudwigLevel *L, void *hip_stream)
+{
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    L->stream = (hipStream_t)hip_stream;
+    return LUDWIG_OK;
+}
+
+int ludwig_level_set_order(LudwigLevel *L, int part, const int32_t *items, int64_t n_items)
+{
+    if (!L || (!items && n_items > 0)) return fail(LUDWIG_ERR_INVALID, "null argument");
+    if (part < 0 || part >= N_PARTS) return fail(LUDWIG_ERR_INVALID, "bad part %d", part);
+    LW_HIP(hipSetDevice(L->device));
+    LW_HIP(hipStreamSynchronize(L->stream));
+    // every (block, half) of the part exactly once
+    std::vector<uint8_t> seen((size_t)L->n_owned * 2, 0);
+    int64_t expect = 0;
+    for (int b = 0; b < L->n_owned; ++b)
+        if (block_in_part(L, b, part)) expect += 2;
+    if (n_items != expect) return fail(LUDWIG_ERR_INVALID, "order has %lld items, part has %lld", (long long)n_items, (long long)expect);
+    for (int64_t i = 0; i < n_items; ++i) {
+        const int b = items[i] >> 3, half = (items[i] & 7) >> 2;
+        if (b < 0 || b >= L->n_owned || (items[i] & 3)) return fail(LUDWIG_ERR_INVALID, "bad work item %lld", (long long)i);
+        if (seen[(size_t)b * 2 + half]++) return fail(LUDWIG_ERR_INVALID, "work item %lld listed twice", (long long)i);
+    }
+    return set_items(L, part, items, n_items);
+}
+
+int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t bytes)
+{
+    if (!L || !host) return fail(LUDWIG_ERR_INVALID, "null argument");
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
+    if (bytes != d.bytes) return fail(LUDWIG_ERR_INVALID, "field %d: got %zu bytes, expected %zu", field, bytes, d.bytes);
+    LW_HIP(hipSetDevice(L->device));
+    LW_HIP(hipMemcpyAsync(d.ptr, host, bytes, hipMemcpyHostToDevice, L->stream));
+    LW_HIP(hipStreamSynchronize(L->stream));
+    if (field == LUDWIG_OBSTACLE || field == LUDWIG_SPONGE || field == LUDWIG_WALL_DIST) {
+        scan_flags(L, field, host);
+        return upload_meta(L);
+    }
+    return LUDWIG_OK;
+}
+
+int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t bytes)
+{
+    if (!L || !host) return fail(LUDWIG_ERR_INVALID, "null argument");
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
+    if (bytes != d.bytes) return fail(LUDWIG_ERR_INVALID, "field %d: got %zu bytes, expected %zu", field, bytes, d.bytes);
+    LW_HIP(hipSetDevice(L->device));
+    LW_HIP(hipMemcpyAsync(host, d.ptr, bytes, hipMemcpyDeviceToHost, L->stream));
+    LW_HIP(hipStreamSynchronize(L->stream));
+    return LUDWIG_OK;
+}
+
+int ludwig_level_field_ptr(const LudwigLevel *L, int field, void **device_ptr, size_t *bytes)
+{
+    if (!L || !device_ptr) return fail(LUDWIG_ERR_INVALID, "null argument");
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
+    *device_ptr = d.ptr;
+    if (bytes) *bytes = d.bytes;
+    return LUDWIG_OK;
+}
+
+int ludwig_init_equilibrium(LudwigLevel *L)
+{
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    if (L->n_blocks == 0) return LUDWIG_OK;
+    LW_HIP(hipSetDevice(L->device));
+    const unsigned grid = (unsigned)((L->sk + 255) / 256);
+    hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[0], L->sk);
+    hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[1], L->sk);
+    if (L->has_temporal) {
+        hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f_old, L->sk);
+        int r = fill(L, L->rho_old, L->sk, 1.0f);
+        if (r) return r;
+        LW_HIP(hipMemsetAsync(L->vel_old, 0, (size_t)L->sk * 3 * 4, L->stream));
+    }
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+int ludwig_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float u_curr, float parent_tau,
+                          float temporal_weight, const LudwigStepFlags *flags, int part)
+{
+    return launch_stream_collide(L, parent, t_sub, u_curr, parent_tau, temporal_weight, flags, part);
+}
+
+int ludwig_bouzidi_correction(LudwigLevel *L, int64_t t_sub, float q_min_threshold) { return launch_bouzidi(L, t_sub, q_min_threshold); }
+
+int ludwig_step(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float u_curr, float parent_tau, float temporal_weight,
+                const LudwigStepFlags *flags)
+{
+    int r = launch_stream_collide(L, parent, t_sub, u_curr, parent_tau, temporal_weight, flags, LUDWIG_PART_ALL);
+    if (r) return r;
+    return launch_bouzidi(L, t_sub, flags->q_min_threshold);
+}
+
+int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
+{
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    if (!L->has_temporal) return LUDWIG_OK;   // reference src/blocks.jl:200
+    LW_HIP(hipSetDevice(L->device));
+    const int in = (t_sub % 2 == 0) ? 0 : 1;
+    const size_t c = (size_t)L->sk;
+    LW_HIP(hipMemcpyAsync(L->f_old, L->f[in], c * Q * 4, hipMemcpyDeviceToDevice, L->stream));
+    LW_HIP(hipMemcpyAsync(L->rho_old, L->rho, c * 4, hipMemcpyDeviceToDevice, L->stream));
+    LW_HIP(hipMemcpyAsync(L->vel_old, L->vel[in], c * 3 * 4, hipMemcpyDeviceToDevice, L->stream));
+    return LUDWIG_OK;
+}
+
+int ludwig_sync(const LudwigLevel *L)
+{
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    LW_HIP(hipSetDevice(L->device));
+    LW_HIP(hipStreamSynchronize(L->stream));
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, float *dst_dev)
+{
+    if (!L || (n > 0 && (!index_dev || !dst_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
+    if (n == 0) return LUDWIG_OK;
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be packed", field);
+    LW_HIP(hipSetDevice(L->device));
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L->stream, (const float *)d.ptr, index_dev, n, dst_dev);
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, const float *src_dev)
+{
+    if (!L || (n > 0 && (!index_dev || !src_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
+    if (n == 0) return LUDWIG_OK;
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be unpacked", field);
+    LW_HIP(hipSetDevice(L->device));
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L->stream, (float *)d.ptr, index_dev, n, src_dev);
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+int ludwig_level_info(const LudwigLevel *L, LudwigLevelInfo *info)
+{
+    if (!L || !info) return fail(LUDWIG_ERR_INVALID, "null argument");
+    info->n_blocks = L->n_blocks;
+    info->n_owned = L->n_owned;
+    info->n_fast_blocks = L->n_fast_blocks;
+    info->n_general_blocks = L->n_owned - L->n_fast_blocks;
+    info->n_boundary_cells = L->n_bc;
+    info->has_temporal_storage = L->has_temporal;
+    info->has_post_collision = L->has_post;
+    info->device_bytes = L->device_bytes;
+    return LUDWIG_OK;
+}
+
+}  // extern "C"

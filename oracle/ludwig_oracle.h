@@ -1,0 +1,106 @@
+/*
+ * ludwig_oracle.h - CPU restatement of the OPEN_Ludwig collide-and-stream hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY. Nothing under open_ludwig_amd/ may import, link or call
+ * this. It exists so that tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg can check the HIP path against an independent scalar implementation.
+ *
+ * PARITY STATUS: "parity unpinned" at unit level - the reference ships no unit-level
+ * golden vectors and its language runtime (Julia) is absent from this image, so it
+ * cannot be run here. The restatement follows the reference
+ * source line by line (citations at every function in ludwig_oracle.c) and is anchored
+ * by analytic invariants (tests/test_oracle_invariants.py) and, once the host
+ * pre-processing rows N1/N2 exist, by the run logs the reference ships.
+ *
+ * All arrays use the reference's memory layout (src/blocks.jl:118-150): Julia
+ * column-major A[x,y,z,b,k]  ->  linear (x-1) + 8(y-1) + 64(z-1) + 512(b-1) + 512*n_blocks*(k-1).
+ * Index tables keep the reference's 1-based values with 0 = absent.
+ */
+#ifndef LUDWIG_ORACLE_H
+#define LUDWIG_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirrors BlockLevel (src/blocks.jl:16-65); only the fields the hot path touches. */
+typedef struct OracleLevel {
+    int32_t level_id;            /* 1-based */
+    int32_t n_blocks;
+    float   tau;
+    int32_t grid_dim_x, grid_dim_y, grid_dim_z;   /* dims of block_pointer */
+    const int32_t *block_pointer;   /* [dim_x,dim_y,dim_z] column-major, 1-based, 0 = absent */
+    const int32_t *neighbor_table;  /* [n_blocks,27] column-major, 1-based, 0 = absent */
+    const int32_t *map_x, *map_y, *map_z;  /* [n_blocks] 1-based block coords */
+    float *rho;                  /* [8,8,8,nb] */
+    float *vel, *vel_temp;       /* [8,8,8,nb,3] */
+    float *f, *f_temp;           /* [8,8,8,nb,27] */
+    float *f_post_collision;     /* [8,8,8,nb,27] or 27-element dummy */
+    float *f_old, *rho_old, *vel_old;
+    int32_t has_temporal_storage;    /* length(f_old) > 27, src/blocks.jl:208 */
+    const uint8_t *obstacle;     /* [8,8,8,nb] Bool */
+    const float *sponge;
+    const float *wall_dist;
+    int32_t bouzidi_enabled;
+    int32_t n_boundary_cells;
+    const uint16_t *bouzidi_q_map;   /* Float16 bits [8,8,8,nb,27] */
+    const int32_t *bouzidi_cell_block;
+    const int8_t *bouzidi_cell_x, *bouzidi_cell_y, *bouzidi_cell_z;
+} OracleLevel;
+
+/* The scalar arguments execute_timestep_batch! forwards (src/solver_control.jl:145-161). */
+typedef struct OracleParams {
+    int32_t domain_nx, domain_ny, domain_nz;   /* coarse (level-1) cell dims */
+    int32_t is_symmetric;                      /* SYMMETRIC_ANALYSIS */
+    int32_t wall_model_active;
+    int32_t use_temporal_interp;
+    int32_t sponge_blend_distributions;
+    float c_wale;
+    float nu_sgs_background;
+    float inlet_turbulence;
+    float q_min_threshold;
+} OracleParams;
+
+/* Kernel-level entry points (one reference @kernel each). */
+void oracle_stream_collide(const OracleLevel *level, const OracleLevel *parent_or_null,
+                           const float *parent_f, const float *parent_vel,
+                           float tau_parent,
+                           float *f_out, const float *f_in,
+                           float *vel_out, const float *vel_in,
+                           float u_inlet, int64_t timestep, float temporal_weight,
+                           const OracleParams *p);
+
+void oracle_bouzidi_correction(const OracleLevel *level, float *f_out, float q_min_threshold);
+
+/* perform_timestep_v2! (src/physics_v2.jl:26-97): stream-collide then Bouzidi. */
+void oracle_perform_timestep(const OracleLevel *level, const OracleLevel *parent_or_null,
+                             const float *parent_f, const float *parent_vel, float tau_parent,
+                             float *f_out, const float *f_in, float *vel_out, const float *vel_in,
+                             float u_inlet, int64_t timestep, float temporal_weight,
+                             const OracleParams *p);
+
+/* execute_timestep_batch! (src/solver_control.jl:145-165). t_start is 1-based like the reference. */
+void oracle_execute_timestep_batch(OracleLevel *levels, int32_t n_levels,
+                                   int64_t t_start, int32_t batch_size, float u_curr,
+                                   const OracleParams *p);
+
+/* init_eq! (src/main.jl:109-134) */
+void oracle_init_equilibrium(OracleLevel *level);
+
+/* ramp factor (src/main.jl:173): returns prog so that u_curr = U_TARGET * prog */
+float oracle_ramp_progress(int64_t batch_end, int64_t ramp_steps);
+
+/* helpers exposed for unit tests */
+float    oracle_gradient_noise(int32_t gx, int32_t gy, int32_t gz, int32_t seed);
+float    oracle_half_to_float(uint16_t h);
+void     oracle_lattice(int32_t *cx, int32_t *cy, int32_t *cz, float *w,
+                        int32_t *opp, int32_t *mirror_y, int32_t *mirror_z);
+int      oracle_num_threads(void);
+void     oracle_set_num_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
