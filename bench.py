@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py - MLUPS of the collide-and-stream hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path (pull-stream + regularised-BGK/WALE collide; no Bouzidi cells in this workload)
+over every cell of a synthetic uniform periodic box, inputs resident in HBM when the timed region starts.
+
+  N = 1 : BASELINE configs[1] - 256^3 periodic box, D3Q27 reg-BGK + WALE, FP32 (SURVEY.md section 8d "C2").
+  N > 1 : weak scaling - every rank owns a 256^3 brick of one global periodic box (8 ranks = configs[3], 512^3),
+          one-cell halo of f and u exchanged every step over RCCL (torch.distributed backend "nccl").
+
+Prints ONE JSON line (rank 0). `roofline` prices the stream-collide kernel against the 8 TB/s HBM peak with the
+algorithmic 216 B per lattice update; `cpu_baseline` is the CPU oracle (a port, NOT the reference's Julia CPU
+path, which cannot run here) timed on a bounded 64^3 sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_LUP = 216.0        # 27 x 4 B read + 27 x 4 B write
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--size", type=int, default=256, help="cells per side of the per-GPU brick")
+    ap.add_argument("--order", default=None, help="launch-order builder (open_ludwig_amd/order.py); default = library default")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-size", type=int, default=64)
+    ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: exchange halos after the whole step")
+    return ap.parse_args()
+
+
+def cpu_baseline(size: int, seconds: float):
+    """Oracle (a port of the reference's arithmetic, all host cores via OpenMP) on a size^3 periodic Taylor-Green box
+    with the bench parameters; steps until the time budget is used."""
+    import numpy as np
+    from open_ludwig_amd import cases
+    from oracle import oracle
+    nb = size // 8
+    grids, params = cases.periodic_box((nb, nb, nb))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    oracle.set_num_threads(cores)
+    oracle.execute_timestep_batch(grids, 1, 1, np.float32(0.0), params)   # touch pages
+    t0 = time.perf_counter()
+    steps = 0
+    t = 2
+    while time.perf_counter() - t0 < seconds:
+        oracle.execute_timestep_batch(grids, t, 2, np.float32(0.0), params)
+        t += 2
+        steps += 2
+    dt = time.perf_counter() - t0
+    return {"value": round(size ** 3 * steps / dt / 1e6, 3), "unit": "MLUPS", "cores": cores, "kind": "port",
+            "sample": f"{size}^3 periodic box, same parameters, {steps} steps in {dt:.1f} s (CPU oracle, OpenMP)"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch   # first: its bundled HIP runtime is the one the whole process shares (same SONAME as /opt/rocm's)
+    from open_ludwig_amd import _lib, adapt, cases, order as order_mod
+    from open_ludwig_amd.physics import stream_collide
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    nb = args.size // 8
+    cells_per_rank = (nb * 8) ** 3
+    stream = torch.cuda.current_stream()
+
+    if world == 1:
+        grids, params = cases.periodic_box((nb, nb, nb))
+        level = adapt(grids[0], local_rank)
+        coords = np.asarray(grids[0].active_block_coords)
+        del grids
+        level.set_stream(stream.cuda_stream)
+        if args.order:
+            level.set_order(order_mod.build(args.order, coords))
+        runner = None
+
+        def step(t):
+            stream_collide(level, None, np.float32(0.5), np.float32(0.0), params, t)
+    else:
+        from open_ludwig_amd import partition
+        runner = partition.periodic_weak_scaling_box(rank, world, (nb, nb, nb), device=local_rank,
+                                                      overlap=not args.no_overlap, order=args.order)
+        level = runner.level
+
+        def step(t):
+            runner.step(t)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t = 1
+    for _ in range(args.warmup):
+        step(t); t += 1
+    barrier()
+    # timed region: EXACTLY --steps steps; per-launch kernel time from events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        step(t); t += 1
+        ev[i][1].record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if dist is not None:
+        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+        k = torch.tensor([kern_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kern_ms = float(k.item())
+
+    # sanity: the state must still be finite and the flow non-trivial (no skipped work)
+    rho = level.download("rho")
+    ok = bool(np.isfinite(rho).all() and rho.std() > 0)
+
+    if rank == 0:
+        total_cells = cells_per_rank * world
+        ms_per_step = wall / args.steps * 1e3
+        mlups = total_cells * args.steps / wall / 1e6
+        achieved = ALGO_BYTES_PER_LUP * cells_per_rank / (kern_ms * 1e-3) / 1e9      # GB/s, one launch on one GPU
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("cells_per_launch") == cells_per_rank:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MLUPS (million lattice updates/s) at 256^3 D3Q27; % of HBM roofline",
+            "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.size}^3 uniform periodic box per GPU, D3Q27 regularized-BGK + WALE, "
+                                   f"Taylor-Green start (SURVEY 8d C2)" + ("" if world == 1 else f"; {world} bricks, one-cell halo of f,u per step over RCCL"),
+                       "cells_per_gpu": cells_per_rank, "global_cells": total_cells, "tau": 0.5006, "c_wale": 0.5,
+                       "nu_sgs_background": 0.0005, "launch_order": args.order or "library default",
+                       "parallelism": "single GPU" if world == 1 else f"spatial domain decomposition x{world}",
+                       "state_finite": ok},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "lw::k_stream_collide<false>", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_LUP * cells_per_rank,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("state went non-finite or trivial during the benchmark")
+
+
+if __name__ == "__main__":
+    main()

@@ -119,7 +119,8 @@ int  ludwig_level_set_stream(LudwigLevel *level, void *hip_stream);
 
 /*
  * Launch order of the stream-collide workgroups. items[i] = (block0 << 3) | z0 with block0 0-based and
- * z0 in {0,4}: one 256-thread workgroup steps z-planes z0..z0+3 of that block. Purely a performance
+ * z0 in {0,4}: one 256-thread workgroup steps z-planes z0..z0+3 of that block; a negative item is a no-op
+ * workgroup (padding, so that slot g of the list can be aimed at XCD g % 8). Purely a performance
  * knob (L2 / Infinity-Cache locality); results do not depend on it. Default: see DESIGN.md.
  */
 int  ludwig_level_set_order(LudwigLevel *level, int part, const int32_t *items, int64_t n_items);
@@ -170,7 +171,7 @@ int  ludwig_halo_unpack(LudwigLevel *level, int field, const int64_t *index_dev,
 /* ---- introspection for benchmarks ---- */
 typedef struct LudwigLevelInfo {
     int32_t n_blocks, n_owned;
-    int32_t n_fast_blocks;        /* blocks with all 26 neighbours present, no obstacle/sponge/wall work */
+    int32_t n_fast_blocks;        /* owned blocks with all 26 neighbours present (branch-free pull kernel) */
     int32_t n_general_blocks;
     int32_t n_boundary_cells;
     int32_t has_temporal_storage, has_post_collision;

@@ -241,6 +241,7 @@ template <bool GENERAL>
 __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
 {
     const int item = p.items[blockIdx.x];
+    if (item < 0) return;                                   // padding slot of an XCD-aligned launch order
     const int b = item >> 3;
     const int z = (item & 7) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform z-plane, 0-based
     const int lane = threadIdx.x & 63;

@@ -155,6 +155,7 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
 {
     std::vector<int32_t> cls[N_CLASSES];
     for (int64_t i = 0; i < n; ++i) {
+        if (items[i] < 0) { cls[0].push_back(-1); continue; }   // no-op slot: keeps the slot -> XCD alignment of class 0
         const int b = items[i] >> 3, z0 = items[i] & 7;
         if (b < 0 || b >= L->n_owned || (z0 != 0 && z0 != 4)) return fail(LUDWIG_ERR_INVALID, "work item %lld = (block %d, z0 %d) is not valid", (long long)i, b, z0);
         if (!block_in_part(L, b, part)) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not in part %d", (long long)i, b, part);
@@ -457,8 +458,11 @@ int ludwig_level_set_order(LudwigLevel *L, int part, const int32_t *items, int64
     int64_t expect = 0;
     for (int b = 0; b < L->n_owned; ++b)
         if (block_in_part(L, b, part)) expect += 2;
-    if (n_items != expect) return fail(LUDWIG_ERR_INVALID, "order has %lld items, part has %lld", (long long)n_items, (long long)expect);
+    int64_t real = 0;
+    for (int64_t i = 0; i < n_items; ++i) real += items[i] >= 0;
+    if (real != expect) return fail(LUDWIG_ERR_INVALID, "order has %lld work items, part has %lld", (long long)real, (long long)expect);
     for (int64_t i = 0; i < n_items; ++i) {
+        if (items[i] < 0) continue;
         const int b = items[i] >> 3, half = (items[i] & 7) >> 2;
         if (b < 0 || b >= L->n_owned || (items[i] & 3)) return fail(LUDWIG_ERR_INVALID, "bad work item %lld", (long long)i);
         if (seen[(size_t)b * 2 + half]++) return fail(LUDWIG_ERR_INVALID, "work item %lld listed twice", (long long)i);
