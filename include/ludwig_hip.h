@@ -118,10 +118,11 @@ void ludwig_level_destroy(LudwigLevel *level);
 int  ludwig_level_set_stream(LudwigLevel *level, void *hip_stream);
 
 /*
- * Launch order of the stream-collide workgroups. items[i] = (block0 << 3) | z0 with block0 0-based and
- * z0 in {0,4}: one 256-thread workgroup steps z-planes z0..z0+3 of that block; a negative item is a no-op
- * workgroup (padding, so that slot g of the list can be aimed at XCD g % 8). Purely a performance
- * knob (L2 / Infinity-Cache locality); results do not depend on it. Default: see DESIGN.md.
+ * Launch order of the stream-collide kernel. One item per WAVE: items[i] = (block0 << 3) | z with block0 0-based
+ * and z in 0..7 = the 8x8 z-plane of that block the wave steps; a negative item is an idle wave. Four consecutive
+ * items form one 256-thread workgroup, and workgroup g (items 4g..4g+3) is expected on XCD g % 8. Every
+ * (block, plane) of the part must appear exactly once. Purely a performance knob (L2 / Infinity-Cache
+ * locality); results do not depend on it. Default: "plane-per-XCD", see DESIGN.md.
  */
 int  ludwig_level_set_order(LudwigLevel *level, int part, const int32_t *items, int64_t n_items);
 

@@ -8,8 +8,9 @@
 // finite inputs. Multiplications by the lattice constants 0/+1/-1 are resolved at compile time
 // (x*1 = x, x*-1 = -x exactly; a dropped x*0 term only changes the sign of an exact zero).
 //
-// Mapping: one 64-lane wavefront = one 8x8 z-plane of one 8^3 block (lane = x + 8y), a 256-thread
-// workgroup = 4 consecutive z-planes. The block index and z are wave-uniform, so the 27 neighbour
+// Mapping: one 64-lane wavefront = one 8x8 z-plane of one 8^3 block (lane = x + 8y); a 256-thread
+// workgroup = 4 such planes chosen by the host's work list (by default the same plane of 2x2 x/y-adjacent
+// blocks, see ludwig_hip.hip). The block index and z are wave-uniform, so the 27 neighbour
 // block ids come through the scalar cache and each population load is one coalesced 256-B access
 // (plus the face/edge lanes that reach into a neighbour block).
 #pragma once
@@ -33,7 +34,7 @@ struct SCParams {
     const float *sponge;
     const float *wall_dist;
     const int32_t *meta;      // [n_blocks][NBR_STRIDE]
-    const int32_t *items;     // work list: (block << 3) | z0
+    const int32_t *items;     // work list, one entry per wave: (block << 3) | z, or -1
     int64_t sk;               // population stride in elements = 512 * n_blocks
     // parent level (coarse -> fine interface), unused on level 1
     const float *pf_new, *pf_old, *prho_new, *prho_old, *pvel_new, *pvel_old;
@@ -218,73 +219,133 @@ __device__ __noinline__ void wall_model_force(float dist_wall, float tau_molecul
     }
 }
 
-// previous-step velocity of the face neighbour (dx,dy,dz), reference src/physics_utils.jl:45-70
-template <int DX, int DY, int DZ, bool GENERAL>
-__device__ __forceinline__ void velocity_neighbor(const SCParams &p, const int32_t *meta, int b, int x, int y, int z,
-                                                  float &u1, float &u2, float &u3)
+// ---- addressing helpers -------------------------------------------------------------------------------------
+// Every access is `wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset`, which gfx950 encodes as
+// global_load/store_dword v, v_off, s[base:base+1] - no 64-bit vector address arithmetic. The byte offset of a
+// cell inside one population is (block * 512 + cell) * 4 < 2^32 (checked at level creation).
+__device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off)
 {
-    const int nx = x + DX, ny = y + DY, nz = z + DZ;          // 0-based
-    const bool out = (DX != 0 && (nx < 0 || nx > 7)) || (DY != 0 && (ny < 0 || ny > 7)) || (DZ != 0 && (nz < 0 || nz > 7));
-    const int nb = meta[DIR(DX, DY, DZ)];                     // wave-uniform
-    int blk = out ? nb : b;
-    int cell = (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7);
-    if constexpr (GENERAL) {
-        if (blk < 0) { blk = b; cell = x + 8 * y + 64 * z; }  // missing neighbour block -> own value
-    }
-    const uint32_t off = (uint32_t)blk * CELLS + cell;
-    u1 = p.vel_in[off];
-    u2 = (p.vel_in + p.sk)[off];
-    u3 = (p.vel_in + 2 * p.sk)[off];
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v)
+{
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 
-template <bool GENERAL>
+// The 27 neighbour block ids of the wave's block, held in SGPRs, regrouped by source z-layer:
+// id[g][j] for g = 0 (cz=+1: source plane z-1), 1 (cz=0), 2 (cz=-1: source plane z+1), j = (ox+1) + 3(oy+1).
+struct NeighbourIds {
+    int id[3][9];
+    int zs[3];      // source plane index inside the source block
+};
+
+__device__ __forceinline__ NeighbourIds load_neighbour_ids(const int32_t *__restrict__ meta, int z)
+{
+    int nb[27];
+#pragma unroll
+    for (int d = 0; d < 27; ++d) nb[d] = meta[d];            // wave-uniform -> scalar loads, one burst
+    NeighbourIds n;
+    const bool z_lo = z == 0, z_hi = z == 7;                 // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int lo = nb[j], mid = nb[9 + j], hi = nb[18 + j];   // values, not lvalues (see source_block)
+        n.id[0][j] = z_lo ? lo : mid;
+        n.id[1][j] = mid;
+        n.id[2][j] = z_hi ? hi : mid;
+    }
+    n.zs[0] = (z - 1) & 7; n.zs[1] = z; n.zs[2] = (z + 1) & 7;
+    return n;
+}
+
+// per-lane position inside the 8x8 plane and the face flags the pull needs
+struct LanePos {
+    int x, y;
+    bool x0, x7, y0, y7;
+};
+
+// source block id (per lane) of population k: own block or the x / y / xy neighbour in the layer cz selects
+template <int K>
+__device__ __forceinline__ int source_block(const NeighbourIds &n, const LanePos &l)
+{
+    constexpr int cx = CX(K), cy = CY(K), g = 1 - CZ(K);
+    const bool xo = cx == 1 ? l.x0 : (cx == -1 ? l.x7 : false);
+    const bool yo = cy == 1 ? l.y0 : (cy == -1 ? l.y7 : false);
+    // copy to values first: a ?: between array ELEMENTS is an lvalue select, which keeps the table in scratch memory
+    const int c00 = n.id[g][4], cX = n.id[g][4 - cx], cY = n.id[g][4 - 3 * cy], cXY = n.id[g][4 - cx - 3 * cy];
+    int sel = c00;
+    if constexpr (cx != 0 && cy != 0) sel = xo ? (yo ? cXY : cX) : (yo ? cY : c00);
+    else if constexpr (cx != 0) sel = xo ? cX : c00;
+    else if constexpr (cy != 0) sel = yo ? cY : c00;
+    return sel;
+}
+// byte offset of the pulled cell inside its source block
+template <int K>
+__device__ __forceinline__ uint32_t source_cell_bytes(const NeighbourIds &n, const LanePos &l)
+{
+    constexpr int cx = CX(K), cy = CY(K), g = 1 - CZ(K);
+    return (uint32_t)((((l.x - cx) & 7) + 8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(n.zs[g] * 256);
+}
+
+// previous-step velocity of the face neighbour (dx,dy,dz), reference src/physics_utils.jl:45-70
+template <int DX, int DY, int DZ, bool GENERAL>
+__device__ __forceinline__ void velocity_neighbor(const SCParams &p, const NeighbourIds &n, const LanePos &l, int b, int z,
+                                                  uint32_t own_bytes, float &u1, float &u2, float &u3)
+{
+    constexpr int g = 1 + DZ;   // layer that holds the neighbour when it lies outside the block in z
+    bool out;
+    int nbid;
+    if constexpr (DX != 0) { out = DX == 1 ? l.x7 : l.x0; nbid = n.id[1][4 + DX]; }
+    else if constexpr (DY != 0) { out = DY == 1 ? l.y7 : l.y0; nbid = n.id[1][4 + 3 * DY]; }
+    else { out = DZ == 1 ? (z == 7) : (z == 0); nbid = DZ == 1 ? n.id[2][4] : n.id[0][4]; }
+    (void)g;
+    const int blk = out ? nbid : b;
+    uint32_t off = (uint32_t)blk * (CELLS * 4) +
+                   (uint32_t)((((l.x + DX) & 7) + 8 * ((l.y + DY) & 7) + 64 * ((z + DZ) & 7)) * 4);
+    if constexpr (GENERAL) {
+        if (blk < 0) off = own_bytes;   // missing neighbour block -> own value
+    }
+    u1 = ld_f32(p.vel_in, off);
+    u2 = ld_f32(p.vel_in + p.sk, off);
+    u3 = ld_f32(p.vel_in + 2 * p.sk, off);
+}
+
+// GENERAL: blocks with a missing neighbour (domain edge / refinement interface); POST: also store f_post_collision
+// (level has Bouzidi cells); WALL: wall model active.
+template <bool GENERAL, bool POST, bool WALL>
 __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
 {
-    const int item = p.items[blockIdx.x];
+    // one work item per WAVE: (block << 3) | z. Which waves share a workgroup / an XCD is the host's choice (order.py).
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = p.items[blockIdx.x * 4 + wave];
     if (item < 0) return;                                   // padding slot of an XCD-aligned launch order
     const int b = item >> 3;
-    const int z = (item & 7) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform z-plane, 0-based
+    const int z = item & 7;                                 // wave-uniform z-plane, 0-based
     const int lane = threadIdx.x & 63;
-    const int x = lane & 7, y = lane >> 3;
+    LanePos l;
+    l.x = lane & 7; l.y = lane >> 3;
+    l.x0 = l.x == 0; l.x7 = l.x == 7; l.y0 = l.y == 0; l.y7 = l.y == 7;
     const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
     const int flags = meta[NBR_FLAGS];
-    const int own_cell = x + 8 * y + 64 * z;
-    const uint32_t own = (uint32_t)b * CELLS + own_cell;
+    const NeighbourIds nbr = load_neighbour_ids(meta, z);
+    const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
 
     // ---- pull-stream, reference src/physics_kernels.jl:62-149 ----
     float fs[Q];
-    float rho = 0.0f, jx = 0.0f, jy = 0.0f, jz = 0.0f;
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
-        const int sz = z - cz;                                   // wave-uniform
-        const int oz = sz < 0 ? -1 : (sz > 7 ? 1 : 0);
-        const bool xo = cx == 1 ? (x == 0) : (cx == -1 ? (x == 7) : false);
-        const bool yo = cy == 1 ? (y == 0) : (cy == -1 ? (y == 7) : false);
-        const int cell = ((x - cx) & 7) + 8 * ((y - cy) & 7) + 64 * (sz & 7);
-        // source block: own / x- / y- / xy-neighbour in z-layer oz (ids are wave-uniform scalars)
-        const int n00 = meta[DIR(0, 0, 0) + 9 * oz];
-        int sel = n00;
-        if constexpr (cx != 0 && cy != 0) {
-            const int nX = meta[DIR(-cx, 0, 0) + 9 * oz], nY = meta[DIR(0, -cy, 0) + 9 * oz], nXY = meta[DIR(-cx, -cy, 0) + 9 * oz];
-            sel = xo ? (yo ? nXY : nX) : (yo ? nY : n00);
-        } else if constexpr (cx != 0) {
-            const int nX = meta[DIR(-cx, 0, 0) + 9 * oz];
-            sel = xo ? nX : n00;
-        } else if constexpr (cy != 0) {
-            const int nY = meta[DIR(0, -cy, 0) + 9 * oz];
-            sel = yo ? nY : n00;
-        }
-        const float *__restrict__ fk = p.f_in + p.sk * k;
-        float val;
+        const int sel = source_block<k>(nbr, l);
+        const uint32_t off = (uint32_t)sel * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
+        const float *fk = p.f_in + p.sk * k;
         if constexpr (!GENERAL) {
-            val = fk[(uint32_t)sel * CELLS + cell];
+            fs[k] = ld_f32(fk, off);
         } else {
+            float val;
             if (sel >= 0) {
-                val = fk[(uint32_t)sel * CELLS + cell];
+                val = ld_f32(fk, off);
             } else {
                 // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
-                const int gx = (meta[NBR_BX] - 1) * BS + x + 1, gy = (meta[NBR_BY] - 1) * BS + y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
+                const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
                 const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
                 const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
                 const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
@@ -300,41 +361,55 @@ __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
                     const float cu_out = (float)cx * p.u_inlet;
                     val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
                 } else if (is_y_min && p.is_symmetric == 1) {
-                    val = (p.f_in + p.sk * MIRROR_Y(k))[own];
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
                 } else if (is_y_min || is_y_max) {
-                    val = (p.f_in + p.sk * MIRROR_Y(k))[own];
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
                 } else if (is_z_min || is_z_max) {
-                    val = (p.f_in + p.sk * MIRROR_Z(k))[own];
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
                 } else if (p.is_level_1 == 0) {
                     val = interpolate_with_rescaling(p, src_gx, src_gy, src_gz, k, WEIGHT(k), (float)cx, (float)cy, (float)cz);
                 } else {
                     val = WEIGHT(k);
                 }
             }
+            fs[k] = val;
         }
-        fs[k] = val;
+    });
+    // previous-step velocity of the 6 face neighbours (WALE stencil) - issued with the pulls so that all loads of the
+    // wave are in flight together; reference src/physics_utils.jl:72-83
+    float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
+    velocity_neighbor<1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_E, uy_E, uz_E);
+    velocity_neighbor<-1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_W, uy_W, uz_W);
+    velocity_neighbor<0, 1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_N, uy_N, uz_N);
+    velocity_neighbor<0, -1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_S, uy_S, uz_S);
+    velocity_neighbor<0, 0, 1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_T, uy_T, uz_T);
+    velocity_neighbor<0, 0, -1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_B, uy_B, uz_B);
+
+    // moments in the reference's order: rho += f_k; j += f_k * c_k for k = 1..27
+    float rho = 0.0f, jx = 0.0f, jy = 0.0f, jz = 0.0f;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+        const float val = fs[k];
         rho += val;
         if constexpr (cx == 1) jx += val; else if constexpr (cx == -1) jx -= val;
         if constexpr (cy == 1) jy += val; else if constexpr (cy == -1) jy -= val;
         if constexpr (cz == 1) jz += val; else if constexpr (cz == -1) jz -= val;
     });
 
-    float *__restrict__ f_out = p.f_out;
-    float *__restrict__ f_post = p.f_post;
-
     // ---- obstacle cell: full-way bounce-back of the pulled set, reference :154-166 ----
     bool is_obs = false;
-    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own] != 0;
+    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own_bytes >> 2] != 0;
     if (is_obs) {
-        p.vel_out[own] = 0.0f;
-        (p.vel_out + p.sk)[own] = 0.0f;
-        (p.vel_out + 2 * p.sk)[own] = 0.0f;
-        p.rho[own] = 1.0f;
+        st_f32(p.vel_out, own_bytes, 0.0f);
+        st_f32(p.vel_out + p.sk, own_bytes, 0.0f);
+        st_f32(p.vel_out + 2 * p.sk, own_bytes, 0.0f);
+        st_f32(p.rho, own_bytes, 1.0f);
         static_for<0, Q>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const float f_coll = fs[OPP(k)];
-            (f_out + p.sk * k)[own] = f_coll;
-            if (f_post) (f_post + p.sk * k)[own] = f_coll;
+            st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
+            if constexpr (POST) st_f32(p.f_post + p.sk * k, own_bytes, f_coll);
         });
         return;
     }
@@ -346,7 +421,7 @@ __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
 
     // ---- sponge, reference :181-199 ----
     if (flags & FLAG_HAS_SPONGE) {
-        const float sp = p.sponge[own];
+        const float sp = ld_f32(p.sponge, own_bytes);
         if (sp > 0.0f) {
             const float rho_target = 1.0f, ux_target = p.u_inlet;
             rho = rho * (1.0f - sp) + rho_target * sp;
@@ -364,29 +439,23 @@ __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
         }
     }
 
-    // ---- wall-model force, reference :202-236 ----
+    // ---- wall-model force, reference :202-241 ----
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
-    const bool wall_block = p.wall_model == 1 && (flags & FLAG_HAS_NEAR_WALL);   // wave-uniform
-    if (wall_block) wall_model_force(p.wall_dist[own], p.tau, rho, ux, uy, uz, Fx, Fy, Fz);
-
-    const float ux_eq = ux + 0.5f * Fx * inv_rho;
-    const float uy_eq = uy + 0.5f * Fy * inv_rho;
-    const float uz_eq = uz + 0.5f * Fz * inv_rho;
+    float ux_eq = ux, uy_eq = uy, uz_eq = uz;          // u + 0.5 F / rho with F = 0
+    if constexpr (WALL) {
+        if (flags & FLAG_HAS_NEAR_WALL) wall_model_force(ld_f32(p.wall_dist, own_bytes), p.tau, rho, ux, uy, uz, Fx, Fy, Fz);
+        ux_eq = ux + 0.5f * Fx * inv_rho;
+        uy_eq = uy + 0.5f * Fy * inv_rho;
+        uz_eq = uz + 0.5f * Fz * inv_rho;
+    }
     const float usq_eq = ux_eq * ux_eq + uy_eq * uy_eq + uz_eq * uz_eq;
 
-    p.vel_out[own] = ux;
-    (p.vel_out + p.sk)[own] = uy;
-    (p.vel_out + 2 * p.sk)[own] = uz;
-    p.rho[own] = rho;
+    st_f32(p.vel_out, own_bytes, ux);
+    st_f32(p.vel_out + p.sk, own_bytes, uy);
+    st_f32(p.vel_out + 2 * p.sk, own_bytes, uz);
+    st_f32(p.rho, own_bytes, rho);
 
-    // ---- WALE eddy viscosity from the previous step's velocity, reference :251-300 + physics_utils.jl:72-83 ----
-    float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
-    velocity_neighbor<1, 0, 0, GENERAL>(p, meta, b, x, y, z, ux_E, uy_E, uz_E);
-    velocity_neighbor<-1, 0, 0, GENERAL>(p, meta, b, x, y, z, ux_W, uy_W, uz_W);
-    velocity_neighbor<0, 1, 0, GENERAL>(p, meta, b, x, y, z, ux_N, uy_N, uz_N);
-    velocity_neighbor<0, -1, 0, GENERAL>(p, meta, b, x, y, z, ux_S, uy_S, uz_S);
-    velocity_neighbor<0, 0, 1, GENERAL>(p, meta, b, x, y, z, ux_T, uy_T, uz_T);
-    velocity_neighbor<0, 0, -1, GENERAL>(p, meta, b, x, y, z, ux_B, uy_B, uz_B);
+    // ---- WALE eddy viscosity from the previous step's velocity, reference :251-300 ----
     const float g11 = 0.5f * (ux_E - ux_W), g12 = 0.5f * (ux_N - ux_S), g13 = 0.5f * (ux_T - ux_B);
     const float g21 = 0.5f * (uy_E - uy_W), g22 = 0.5f * (uy_N - uy_S), g23 = 0.5f * (uy_T - uy_B);
     const float g31 = 0.5f * (uz_E - uz_W), g32 = 0.5f * (uz_N - uz_S), g33 = 0.5f * (uz_T - uz_B);
@@ -453,17 +522,17 @@ __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
         acc_signed<cx * cy>(od, od_empty, Pi_xy);
         acc_signed<cy * cz>(od, od_empty, Pi_yz);
         acc_signed<cz * cx>(od, od_empty, Pi_zx);
-        const float f_neq_reg = (w_k * 4.5f) * (Pi_xx * Q_xx + Pi_yy * Q_yy + Pi_zz * Q_zz + 2.0f * od);
-        float f_coll;
-        if (wall_block) {
+        float inner = Pi_xx * Q_xx + Pi_yy * Q_yy + Pi_zz * Q_zz;
+        if constexpr (cx * cy != 0 || cy * cz != 0 || cz * cx != 0) inner = inner + 2.0f * od;   // else + 2*0: exact no-op
+        const float f_neq_reg = (w_k * 4.5f) * inner;
+        float f_coll = feq + one_m_omega * f_neq_reg;
+        if constexpr (WALL) {
             const float force_term = (w_k * 3.0f) * ((cx_f - ux + 3.0f * cu * cx_f) * Fx + (cy_f - uy + 3.0f * cu * cy_f) * Fy +
                                                      (cz_f - uz + 3.0f * cu * cz_f) * Fz);
-            f_coll = feq + one_m_omega * f_neq_reg + one_m_half_omega * force_term;
-        } else {
-            f_coll = feq + one_m_omega * f_neq_reg;   // force_term is an exact zero
+            f_coll = f_coll + one_m_half_omega * force_term;
         }
-        if (f_post) (f_post + p.sk * k)[own] = f_coll;
-        (f_out + p.sk * k)[own] = f_coll;
+        if constexpr (POST) st_f32(p.f_post + p.sk * k, own_bytes, f_coll);
+        st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
     });
 }
 

@@ -153,16 +153,21 @@ bool block_in_part(const LudwigLevel *L, int b, int part)
 
 int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
 {
+    // one item per wave: (block << 3) | z, or -1 = idle wave. 4 consecutive items form one 256-thread workgroup.
     std::vector<int32_t> cls[N_CLASSES];
     for (int64_t i = 0; i < n; ++i) {
-        if (items[i] < 0) { cls[0].push_back(-1); continue; }   // no-op slot: keeps the slot -> XCD alignment of class 0
-        const int b = items[i] >> 3, z0 = items[i] & 7;
-        if (b < 0 || b >= L->n_owned || (z0 != 0 && z0 != 4)) return fail(LUDWIG_ERR_INVALID, "work item %lld = (block %d, z0 %d) is not valid", (long long)i, b, z0);
+        if (items[i] < 0) { cls[0].push_back(-1); continue; }   // idle slot: keeps the slot -> XCD alignment of class 0
+        const int b = items[i] >> 3;
+        if (b < 0 || b >= L->n_owned) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not an owned block", (long long)i, b);
         if (!block_in_part(L, b, part)) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not in part %d", (long long)i, b, part);
         const bool fast = (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0;
         cls[fast ? 0 : 1].push_back(items[i]);
     }
     for (int c = 0; c < N_CLASSES; ++c) {
+        bool any = false;
+        for (int32_t it : cls[c]) any = any || it >= 0;
+        if (!any) cls[c].clear();
+        while (cls[c].size() % 4) cls[c].push_back(-1);
         if (L->items[part][c]) { (void)hipFree(L->items[part][c]); L->items[part][c] = nullptr; }
         L->n_items[part][c] = (int64_t)cls[c].size();
         if (!cls[c].empty()) {
@@ -173,16 +178,39 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
     return LUDWIG_OK;
 }
 
-// Default launch order. Workgroups are dealt round-robin to the 8 XCDs (each with a private L2), so
-// workgroup g runs on XCD g % 8. We hand every XCD a contiguous run of the block list: blocks that are
-// adjacent in the list (z-neighbours in the reference's sort order, bz fastest) then share an L2 while
-// the lines of their common face are hot.
+// Default launch order ("plane-per-XCD").
+// A cache line of population k, z-plane p of a block is read only by waves working on plane p + cz(k): in the
+// owning block and in its x/y neighbours (faces, edges). Nothing is shared across different plane indices.
+// MI355X deals workgroup g to XCD g % 8, each XCD with a private L2, so we give in-block plane z to XCD z:
+// every line is then fetched by exactly one XCD, and the neighbours that re-read it sit in the same workgroup
+// (the same plane of 4 y-adjacent blocks = 4 waves) or in a workgroup the same XCD runs next (patches are swept
+// y-fastest, then x, then block-z). Measured on MI355X at 256^3 against 8 other orders (tools/order_sweep.py,
+// DESIGN.md "Launch order"): L2 read misses 226 -> 168 B/cell, 4-9 % less time than block-by-block order.
 int default_items(LudwigLevel *L, int part)
 {
+    struct Key { int32_t bz, bx, py, by, b; };
+    std::vector<Key> keys;
+    for (int b = 0; b < L->n_owned; ++b) {
+        if (!block_in_part(L, b, part)) continue;
+        const int32_t *row = &L->h_meta[(size_t)b * NBR_STRIDE];
+        keys.push_back({row[NBR_BZ], row[NBR_BX], (row[NBR_BY] - 1) >> 2, row[NBR_BY], b});
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &c) {
+        if (a.bz != c.bz) return a.bz < c.bz;
+        if (a.bx != c.bx) return a.bx < c.bx;
+        if (a.py != c.py) return a.py < c.py;
+        return a.by < c.by;
+    });
+    // patches of up to 4 y-adjacent blocks; workgroup slot g = 8 * patch + z  (-> XCD z)
     std::vector<int32_t> seq;
-    for (int b = 0; b < L->n_owned; ++b)
-        if (block_in_part(L, b, part)) { seq.push_back(b << 3); seq.push_back((b << 3) | 4); }
-    // the fast / general split happens in set_items and keeps relative order; interleave per class there
+    size_t i = 0;
+    while (i < keys.size()) {
+        size_t j = i;
+        while (j < keys.size() && j - i < 4 && keys[j].bz == keys[i].bz && keys[j].bx == keys[i].bx && keys[j].py == keys[i].py) ++j;
+        for (int z = 0; z < 8; ++z)
+            for (size_t w = 0; w < 4; ++w) seq.push_back(i + w < j ? (keys[i + w].b << 3) | z : -1);
+        i = j;
+    }
     return set_items(L, part, seq.data(), (int64_t)seq.size());
 }
 
@@ -241,14 +269,20 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     p.use_temporal = (fl->use_temporal_interp && (!parent || parent->has_temporal)) ? 1 : 0;
     p.sponge_blend = fl->sponge_blend_distributions ? 1 : 0;
 
-    if (L->n_items[part][0] > 0) {
-        p.items = L->items[part][0];
-        hipLaunchKernelGGL(k_stream_collide<false>, dim3((unsigned)L->n_items[part][0]), dim3(256), 0, L->stream, p);
-        LW_HIP(hipGetLastError());
-    }
-    if (L->n_items[part][1] > 0) {
-        p.items = L->items[part][1];
-        hipLaunchKernelGGL(k_stream_collide<true>, dim3((unsigned)L->n_items[part][1]), dim3(256), 0, L->stream, p);
+    const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
+    for (int c = 0; c < N_CLASSES; ++c) {
+        if (L->n_items[part][c] == 0) continue;
+        p.items = L->items[part][c];
+        const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
+#define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, L->stream, p)
+        if (c == 0) {
+            if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
+            else      { if (wall) LW_LAUNCH(false, false, true); else LW_LAUNCH(false, false, false); }
+        } else {
+            if (post) { if (wall) LW_LAUNCH(true, true, true); else LW_LAUNCH(true, true, false); }
+            else      { if (wall) LW_LAUNCH(true, false, true); else LW_LAUNCH(true, false, false); }
+        }
+#undef LW_LAUNCH
         LW_HIP(hipGetLastError());
     }
     return LUDWIG_OK;
@@ -313,7 +347,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     *out = nullptr;
     if (h->n_blocks < 0 || h->level_id < 1 || h->level_id > 30) return fail(LUDWIG_ERR_INVALID, "bad n_blocks/level_id");
     if (h->n_blocks > 0 && (!h->neighbor_table || !h->map_x || !h->map_y || !h->map_z)) return fail(LUDWIG_ERR_INVALID, "neighbor_table and map_x/y/z are required");
-    if ((int64_t)h->n_blocks * CELLS >= (int64_t)1 << 31) return fail(LUDWIG_ERR_INVALID, "n_blocks too large for 32-bit cell offsets");
+    if ((int64_t)h->n_blocks * CELLS * 4 >= (int64_t)1 << 32) return fail(LUDWIG_ERR_INVALID, "n_blocks too large for 32-bit byte offsets (max 2^21 - 1 blocks per level)");
     const int n_owned = h->n_owned > 0 ? h->n_owned : h->n_blocks;
     if (n_owned > h->n_blocks) return fail(LUDWIG_ERR_INVALID, "n_owned > n_blocks");
     int ndev = 0;
@@ -453,20 +487,19 @@ int ludwig_level_set_order(LudwigLevel *L, int part, const int32_t *items, int64
     if (part < 0 || part >= N_PARTS) return fail(LUDWIG_ERR_INVALID, "bad part %d", part);
     LW_HIP(hipSetDevice(L->device));
     LW_HIP(hipStreamSynchronize(L->stream));
-    // every (block, half) of the part exactly once
-    std::vector<uint8_t> seen((size_t)L->n_owned * 2, 0);
-    int64_t expect = 0;
+    // every (block, z-plane) of the part exactly once
+    std::vector<uint8_t> seen((size_t)L->n_owned * 8, 0);
+    int64_t expect = 0, real = 0;
     for (int b = 0; b < L->n_owned; ++b)
-        if (block_in_part(L, b, part)) expect += 2;
-    int64_t real = 0;
-    for (int64_t i = 0; i < n_items; ++i) real += items[i] >= 0;
-    if (real != expect) return fail(LUDWIG_ERR_INVALID, "order has %lld work items, part has %lld", (long long)real, (long long)expect);
+        if (block_in_part(L, b, part)) expect += 8;
     for (int64_t i = 0; i < n_items; ++i) {
         if (items[i] < 0) continue;
-        const int b = items[i] >> 3, half = (items[i] & 7) >> 2;
-        if (b < 0 || b >= L->n_owned || (items[i] & 3)) return fail(LUDWIG_ERR_INVALID, "bad work item %lld", (long long)i);
-        if (seen[(size_t)b * 2 + half]++) return fail(LUDWIG_ERR_INVALID, "work item %lld listed twice", (long long)i);
+        ++real;
+        const int b = items[i] >> 3;
+        if (b >= L->n_owned) return fail(LUDWIG_ERR_INVALID, "bad work item %lld", (long long)i);
+        if (seen[(size_t)items[i]]++) return fail(LUDWIG_ERR_INVALID, "work item %lld listed twice", (long long)i);
     }
+    if (real != expect) return fail(LUDWIG_ERR_INVALID, "order has %lld work items, part has %lld", (long long)real, (long long)expect);
     return set_items(L, part, items, n_items);
 }
 

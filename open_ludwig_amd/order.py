@@ -1,105 +1,106 @@
 """Launch-order builders for the stream-collide kernel (performance only; results never depend on the order).
 
-A work item is (block0 << 3) | z0: one 256-thread workgroup steps z-planes z0..z0+3 of block0. MI355X deals
-consecutive workgroup ids round-robin to its 8 XCDs (workgroup g -> XCD g % 8, each XCD with a private 4 MiB L2;
-MI355X_MICROARCH.md "Workgroup dispatch"), and ids start roughly in order. The pull reads the one-cell face layer of
-up to 26 neighbour blocks, i.e. cache lines that the neighbour block's own workgroup also reads, so the order decides
-whether that second read is an L2 hit, an Infinity-Cache hit or a second HBM fetch.
+One work item per WAVE: (block0 << 3) | z = the 8x8 z-plane `z` of block `block0`; -1 = idle wave. Four consecutive
+items form a 256-thread workgroup. MI355X deals consecutive workgroup ids round-robin to its 8 XCDs (workgroup g ->
+XCD g % 8, each XCD with a private 4 MiB L2; MI355X_MICROARCH.md "Workgroup dispatch"), ids start roughly in order.
 
-Item -1 is a no-op workgroup (used to pad per-XCD sequences to equal length).
+Who shares cache lines: the 128-B lines of population k, plane p of a block are read by the waves working on plane
+p + cz(k) of that block and of its x/y neighbours (face / edge cells) - never by another plane index. So the
+productive grouping is "same plane, x/y-adjacent blocks": inside one workgroup (L1), else on one XCD close in time (L2).
 """
 from __future__ import annotations
-
-from typing import Sequence
 
 import numpy as np
 
 N_XCD = 8
+WAVES = 4
 
 
-def _items(blocks: np.ndarray) -> np.ndarray:
-    """both z-halves of every block, adjacent"""
-    b = np.asarray(blocks, dtype=np.int64)
-    return np.stack([b << 3, (b << 3) | 4], axis=1).reshape(-1)
+def _pad4(a):
+    a = list(a)
+    while len(a) % WAVES:
+        a.append(-1)
+    return a
 
 
-def _per_xcd(seqs: Sequence[np.ndarray]) -> np.ndarray:
-    """slot g = 8*j + x holds the j-th item of XCD x's sequence; shorter sequences are padded with -1"""
+def _per_xcd(seqs) -> np.ndarray:
+    """seqs[x] = list of workgroups (each 4 items) for XCD x; slot g = 8*j + x; short sequences padded with idle WGs"""
     n = max(len(s) for s in seqs)
-    grid = np.full((n, N_XCD), -1, dtype=np.int64)
+    grid = np.full((n, N_XCD, WAVES), -1, dtype=np.int64)
     for x, s in enumerate(seqs):
-        grid[: len(s), x] = s
-    return grid.reshape(-1)
+        if len(s):
+            grid[: len(s), x, :] = np.asarray(s, dtype=np.int64).reshape(-1, WAVES)
+    return grid.reshape(-1).astype(np.int32)
 
 
-def natural(coords: np.ndarray) -> np.ndarray:
-    """reference block order (bx slowest, bz fastest), workgroups round-robin over XCDs"""
-    return _items(np.arange(len(coords))).astype(np.int32)
+def block_planes(coords) -> np.ndarray:
+    """round-1 baseline: a workgroup = 4 consecutive planes of one block, reference block order, round-robin XCDs"""
+    b = np.arange(len(coords), dtype=np.int64)
+    z = np.arange(8, dtype=np.int64)
+    return ((b[:, None] << 3) | z[None, :]).reshape(-1).astype(np.int32)
 
 
-def sorted_blocks(coords: np.ndarray, fastest: str = "x") -> np.ndarray:
-    c = np.asarray(coords)
-    keys = {"x": (c[:, 0], c[:, 1], c[:, 2]), "z": (c[:, 2], c[:, 1], c[:, 0]), "y": (c[:, 1], c[:, 0], c[:, 2])}[fastest]
-    return np.lexsort(keys)
-
-
-def xcd_chunks(coords: np.ndarray, fastest: str = "z") -> np.ndarray:
-    """every XCD sweeps one contiguous eighth of the block list (sorted with `fastest` varying fastest)"""
-    order = sorted_blocks(coords, fastest)
-    it = _items(order)
-    per = -(-len(it) // N_XCD)
-    per += per % 2   # keep both halves of a block on one XCD
-    return _per_xcd([it[x * per:(x + 1) * per] for x in range(N_XCD)]).astype(np.int32)
-
-
-def xcd_rows(coords: np.ndarray, axis: str = "x", group: int = 1) -> np.ndarray:
-    """Rows of blocks along `axis` are dealt to the XCDs round-robin in groups of `group` rows; each XCD sweeps its
-    rows one after the other. All 8 XCDs therefore work in the same neighbourhood at the same time (faces shared
-    between rows meet in the Infinity Cache) while the faces along the row stay inside one L2."""
-    c = np.asarray(coords)
-    ax = "xyz".index(axis)
-    o1, o2 = [a for a in range(3) if a != ax]
-    # row id = (slow other axis, fast other axis)
-    row_keys = c[:, o1].astype(np.int64) * (c[:, o2].max() + 1) + c[:, o2]
-    uniq, row_of = np.unique(row_keys, return_inverse=True)
-    order = np.lexsort((c[:, ax], row_of))            # by row, then along the axis
-    row_sorted = row_of[order]
-    seqs = [[] for _ in range(N_XCD)]
-    starts = np.flatnonzero(np.r_[True, row_sorted[1:] != row_sorted[:-1], True])
-    for r in range(len(starts) - 1):
-        x = (r // group) % N_XCD
-        seqs[x].append(_items(order[starts[r]:starts[r + 1]]))
-    seqs = [np.concatenate(s) if s else np.zeros(0, np.int64) for s in seqs]
-    return _per_xcd(seqs).astype(np.int32)
-
-
-def xcd_tiles(coords: np.ndarray, tile=(4, 4, 4)) -> np.ndarray:
-    """Blocks grouped into tiles of `tile` blocks; tiles dealt round-robin to XCDs; inside a tile x varies fastest."""
+def _patches(coords, px: int, py: int, sweep: str):
+    """group blocks into px x py patches in (bx,by) at equal bz; returns list of arrays of block ids, in sweep order"""
     c = np.asarray(coords).astype(np.int64) - 1
-    t = c // np.array(tile)
-    tdim = t.max(axis=0) + 1
-    tid = (t[:, 2] * tdim[1] + t[:, 1]) * tdim[0] + t[:, 0]
-    inner = c % np.array(tile)
-    order = np.lexsort((inner[:, 0], inner[:, 1], inner[:, 2], tid))
-    tid_sorted = tid[order]
-    starts = np.flatnonzero(np.r_[True, tid_sorted[1:] != tid_sorted[:-1], True])
+    kx, ky, kz = c[:, 0] // px, c[:, 1] // py, c[:, 2]
+    key = {"xyz": (kx, ky, kz), "xzy": (kx, kz, ky), "zxy": (kz, kx, ky), "yxz": (ky, kx, kz)}[sweep]   # fastest first
+    order = np.lexsort((c[:, 0], c[:, 1]) + key)
+    ks = np.stack([kx, ky, kz], 1)[order]
+    cut = np.flatnonzero(np.r_[True, (ks[1:] != ks[:-1]).any(1), True])
+    return [order[cut[i]:cut[i + 1]] for i in range(len(cut) - 1)]
+
+
+def plane_per_xcd(coords, px: int = 2, py: int = 2, sweep: str = "xyz") -> np.ndarray:
+    """XCD z handles in-block plane z of every block; a workgroup = that plane of a px x py patch of blocks (4 waves
+    per workgroup, so larger patches become several consecutive workgroups on the same XCD)."""
     seqs = [[] for _ in range(N_XCD)]
-    for r in range(len(starts) - 1):
-        seqs[r % N_XCD].append(_items(order[starts[r]:starts[r + 1]]))
-    seqs = [np.concatenate(s) if s else np.zeros(0, np.int64) for s in seqs]
-    return _per_xcd(seqs).astype(np.int32)
+    for blocks in _patches(coords, px, py, sweep):
+        for z in range(8):
+            items = _pad4((int(b) << 3) | z for b in blocks)
+            for i in range(0, len(items), WAVES):
+                seqs[z].append(items[i:i + WAVES])
+    return _per_xcd(seqs)
+
+
+def plane_round_robin(coords, px: int = 2, py: int = 2, sweep: str = "xyz") -> np.ndarray:
+    """same workgroups as plane_per_xcd but without aiming planes at XCDs: patch after patch, all 8 planes in turn,
+    for each workgroup of a large patch -> isolates the effect of workgroup grouping from XCD placement"""
+    out = []
+    for blocks in _patches(coords, px, py, sweep):
+        groups = [blocks[i:i + WAVES] for i in range(0, len(blocks), WAVES)]
+        for grp in groups:
+            for z in range(8):
+                out += _pad4((int(b) << 3) | z for b in grp)
+    return np.asarray(out, dtype=np.int32)
+
+
+def columns(coords, tx: int = 1, ty: int = 0) -> np.ndarray:
+    """workgroup = 4 consecutive planes of one block; blocks swept bz-fastest (adjacent memory); the (bx,by) columns
+    are visited in tx x ty tiles (ty = 0: whole y extent, i.e. the reference order when tx = 1)"""
+    c = np.asarray(coords).astype(np.int64) - 1
+    ty_ = ty if ty > 0 else int(c[:, 1].max()) + 1
+    key = (c[:, 2], c[:, 0] % tx + 0 * c[:, 0], c[:, 1] % ty_, c[:, 0] // tx, c[:, 1] // ty_)
+    # fastest first: bz, then x inside tile, y inside tile, then tile x, tile y
+    order = np.lexsort((c[:, 2], c[:, 0] % tx, c[:, 1] % ty_, c[:, 0] // tx, c[:, 1] // ty_))
+    z = np.arange(8, dtype=np.int64)
+    return ((order[:, None] << 3) | z[None, :]).reshape(-1).astype(np.int32)
 
 
 BUILDERS = {
-    "natural": natural,
-    "chunks_z": lambda c: xcd_chunks(c, "z"),
-    "chunks_x": lambda c: xcd_chunks(c, "x"),
-    "rows_x": lambda c: xcd_rows(c, "x", 1),
-    "rows_z": lambda c: xcd_rows(c, "z", 1),
-    "rows_x4": lambda c: xcd_rows(c, "x", 4),
-    "tiles444": lambda c: xcd_tiles(c, (4, 4, 4)),
-    "tiles844": lambda c: xcd_tiles(c, (8, 4, 4)),
-    "tiles882": lambda c: xcd_tiles(c, (8, 8, 2)),
+    "block_planes": block_planes,
+    "pxcd_2x2_xyz": lambda c: plane_per_xcd(c, 2, 2, "xyz"),
+    "pxcd_2x2_zxy": lambda c: plane_per_xcd(c, 2, 2, "zxy"),
+    "pxcd_4x1_xyz": lambda c: plane_per_xcd(c, 4, 1, "xyz"),
+    "pxcd_1x4_yxz": lambda c: plane_per_xcd(c, 1, 4, "yxz"),
+    "pxcd_4x4_xyz": lambda c: plane_per_xcd(c, 4, 4, "xyz"),
+    "pxcd_8x8_xyz": lambda c: plane_per_xcd(c, 8, 8, "xyz"),
+    "pxcd_4x4_zxy": lambda c: plane_per_xcd(c, 4, 4, "zxy"),
+    "prr_2x2_xyz": lambda c: plane_round_robin(c, 2, 2, "xyz"),
+    "cols_xinner": lambda c: columns(c, 1 << 20, 1),
+    "cols_t44": lambda c: columns(c, 4, 4),
+    "cols_t22": lambda c: columns(c, 2, 2),
+    "cols_t88": lambda c: columns(c, 8, 8),
 }
 
 
