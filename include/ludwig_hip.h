@@ -162,12 +162,13 @@ int  ludwig_save_old(LudwigLevel *level, int64_t t_sub);
 int  ludwig_sync(const LudwigLevel *level);
 
 /* ---- halo exchange helpers (no reference counterpart: the reference is single-device) ---- */
-/* dst[i] = field[index[i]] / field[index[i]] = src[i]; index, dst, src are DEVICE pointers,
- * index holds element offsets into the field in the reference layout. */
+/* dst[i] = field[index[i]] / field[index[i]] = src[i]; index, dst, src are DEVICE pointers, index holds element
+ * offsets into the field in the reference layout. hip_stream: the stream to queue on (hipStream_t), NULL = the
+ * level's stream - the exchange normally runs on its own stream so that it overlaps the interior update. */
 int  ludwig_halo_pack(const LudwigLevel *level, int field, const int64_t *index_dev, int64_t n,
-                      float *dst_dev);
+                      float *dst_dev, void *hip_stream);
 int  ludwig_halo_unpack(LudwigLevel *level, int field, const int64_t *index_dev, int64_t n,
-                        const float *src_dev);
+                        const float *src_dev, void *hip_stream);
 
 /* ---- introspection for benchmarks ---- */
 typedef struct LudwigLevelInfo {

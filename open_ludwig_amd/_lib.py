@@ -99,8 +99,8 @@ def load() -> C.CDLL:
         "ludwig_bouzidi_correction": (C.c_int, [vp, i64, f32]),
         "ludwig_save_old": (C.c_int, [vp, i64]),
         "ludwig_sync": (C.c_int, [vp]),
-        "ludwig_halo_pack": (C.c_int, [vp, i32, vp, i64, vp]),
-        "ludwig_halo_unpack": (C.c_int, [vp, i32, vp, i64, vp]),
+        "ludwig_halo_pack": (C.c_int, [vp, i32, vp, i64, vp, vp]),
+        "ludwig_halo_unpack": (C.c_int, [vp, i32, vp, i64, vp, vp]),
         "ludwig_level_info": (C.c_int, [vp, C.POINTER(LevelInfo)]),
     }
     for name, (res, args) in sig.items():

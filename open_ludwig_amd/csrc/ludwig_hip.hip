@@ -596,26 +596,26 @@ int ludwig_sync(const LudwigLevel *L)
     return LUDWIG_OK;
 }
 
-int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, float *dst_dev)
+int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, float *dst_dev, void *hip_stream)
 {
     if (!L || (n > 0 && (!index_dev || !dst_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
     if (n == 0) return LUDWIG_OK;
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be packed", field);
     LW_HIP(hipSetDevice(L->device));
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L->stream, (const float *)d.ptr, index_dev, n, dst_dev);
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
 
-int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, const float *src_dev)
+int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, const float *src_dev, void *hip_stream)
 {
     if (!L || (n > 0 && (!index_dev || !src_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
     if (n == 0) return LUDWIG_OK;
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be unpacked", field);
     LW_HIP(hipSetDevice(L->device));
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, L->stream, (float *)d.ptr, index_dev, n, src_dev);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }

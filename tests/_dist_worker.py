@@ -1,0 +1,69 @@
+"""Worker for the multi-process halo-exchange tests (launched by torch.distributed.run, one process per rank).
+
+mode cpu : gloo, CPU tensors; stepping by the CPU oracle, pack/unpack by numpy -> exercises partition planning, the
+           request hand-shake and HaloExchanger without a GPU.
+mode gpu : gloo with host staging, every rank on cuda:0 (RCCL refuses two ranks on one device); stepping, pack and
+           unpack by libludwig_hip.so through DistributedLevelRunner -> the real N > 1 GPU path minus RCCL itself.
+Each rank writes its owned blocks' newest f / vel / rho to <outdir>/rank<r>.npz.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    mode, outdir, nbx, nby, nbz, steps, overlap = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from open_ludwig_amd import cases, partition
+    from open_ludwig_amd.physics import SolverParams
+    grid = partition.rank_grid(world)
+    nbg = (nbx, nby, nbz)
+    fn, vn = ("f_temp", "vel_temp") if steps % 2 == 0 else ("f", "vel")
+    if mode == "cpu":
+        from oracle import oracle
+        oracle.set_num_threads(2)
+        coords, table, owner = partition.periodic_box_topology(nbg, grid)
+        view = partition.build_local_level(1, coords, table, owner, rank, 0.5006)
+        cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), 0.03)
+        params = SolverParams(domain_nx=8 * nbx, domain_ny=8 * nby, domain_nz=8 * nbz, use_temporal_interp=False)
+        mine = partition.make_requests(view, len(coords))
+        to_me = partition.exchange_requests(mine, world, rank)
+        plan = partition.build_plan(view, len(coords), mine, to_me)
+        lvl = view.level
+
+        def pack(name, idx, out):
+            out.copy_(torch.from_numpy(getattr(lvl, name).reshape(-1, order="F")[idx.numpy()]))
+
+        def unpack(name, idx, src):
+            a = getattr(lvl, name)
+            flat = a.reshape(-1, order="F")
+            flat[idx.numpy()] = src.numpy()
+            a[...] = flat.reshape(a.shape, order="F")
+
+        ex = partition.HaloExchanger(plan, rank, torch.device("cpu"), pack, unpack)
+        for t in range(1, steps + 1):
+            oracle.execute_timestep_batch([lvl], t, 1, np.float32(0.0), params)
+            ex.exchange(*(("f_temp", "vel_temp") if t % 2 == 0 else ("f", "vel")))
+        res = {n: getattr(lvl, n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
+    else:
+        per = tuple(nbg[i] // grid[i] for i in range(3))
+        runner = partition.periodic_weak_scaling_box(rank, world, per, device=0, overlap=bool(overlap), stage_through_host=True)
+        view = runner.view
+        for t in range(1, steps + 1):
+            runner.step(t)
+        runner.synchronize()
+        res = {n: runner.level.download(n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), l2g=view.local_to_global[: view.n_owned], **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""N > 1 path over torch.distributed: 2 processes, gloo. CPU variant runs everywhere; the GPU variant puts both ranks
+on the one MI355X of the test box and stages messages through the host (RCCL needs one device per rank; the driver
+measures the real RCCL path at round end)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from open_ludwig_amd import cases
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(mode, outdir, nbg, steps, world=2, overlap=1):
+    env = dict(os.environ, OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), mode, str(outdir),
+           str(nbg[0]), str(nbg[1]), str(nbg[2]), str(steps), str(overlap)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+
+
+def _check(outdir, nbg, steps, world):
+    grids, params = cases.periodic_box(nbg)
+    oracle.execute_timestep_batch(grids, 1, steps, np.float32(0.0), params)
+    fn, vn = oracle.newest_buffers(0, steps)
+    seen = 0
+    for r in range(world):
+        d = np.load(os.path.join(outdir, f"rank{r}.npz"))
+        for name in (fn, vn, "rho"):
+            assert np.array_equal(d[name], getattr(grids[0], name)[:, :, :, d["l2g"]]), f"rank {r} {name}"
+        seen += d["l2g"].size
+    assert seen == grids[0].n_blocks
+
+
+def test_two_ranks_gloo_cpu(tmp_path):
+    nbg, steps = (4, 2, 2), 3
+    _launch("cpu", tmp_path, nbg, steps, world=2)
+    _check(tmp_path, nbg, steps, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_two_ranks_one_gpu_hip_path(tmp_path, gpu, overlap):
+    nbg, steps = (8, 4, 4), 4
+    _launch("gpu", tmp_path, nbg, steps, world=2, overlap=overlap)
+    _check(tmp_path, nbg, steps, 2)
+
+
+@pytest.mark.gpu
+def test_four_ranks_one_gpu_hip_path(tmp_path, gpu):
+    nbg, steps = (4, 4, 4), 3
+    _launch("gpu", tmp_path, nbg, steps, world=4)
+    _check(tmp_path, nbg, steps, 4)
