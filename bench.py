@@ -40,6 +40,19 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores() -> int:
+    """Cores this process may really use: affinity, capped by the cgroup CPU quota and by the 16-core share a 1-GPU box
+    grants (the box reports 256 logical CPUs but schedules a fraction of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("LUDWIG_BENCH_CPU_CORES", "16"))))
+
+
 def cpu_baseline(size: int, seconds: float):
     """Oracle (a port of the reference's arithmetic, all host cores via OpenMP) on a size^3 periodic Taylor-Green box
     with the bench parameters; steps until the time budget is used."""
@@ -48,7 +61,7 @@ def cpu_baseline(size: int, seconds: float):
     from oracle import oracle
     nb = size // 8
     grids, params = cases.periodic_box((nb, nb, nb))
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     oracle.set_num_threads(cores)
     oracle.execute_timestep_batch(grids, 1, 1, np.float32(0.0), params)   # touch pages
     t0 = time.perf_counter()

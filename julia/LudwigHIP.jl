@@ -1,0 +1,125 @@
+# LudwigHIP.jl - the reference-side binding of libludwig_hip.so (include/ludwig_hip.h).
+#
+# Drop this file next to the reference's src/ and `include("LudwigHIP.jl")` after blocks.jl. It replaces, for an
+# MI355X, the four device-facing calls of the hot path:
+#     adapt(backend, level)                 (src/main.jl:98, src/blocks.jl:67-87)      -> LudwigHIP.adapt_level
+#     perform_timestep_v2!(level, ...)      (src/physics_v2.jl:26-97)                   -> LudwigHIP.perform_timestep!
+#     copy_to_old!(level, f_in, vel_in)     (src/blocks.jl:199-205)                     -> LudwigHIP.copy_to_old!
+#     KernelAbstractions.synchronize        (src/solver_control.jl:164)                 -> LudwigHIP.synchronize
+# NOT TESTED HERE: the build image has no Julia. It is a thin ccall layer; every struct mirrors include/ludwig_hip.h.
+module LudwigHIP
+
+const LIB = get(ENV, "LUDWIG_HIP_LIB", joinpath(@__DIR__, "..", "open_ludwig_amd", "csrc", "libludwig_hip.so"))
+
+# enum LudwigField
+const F, F_TEMP, F_POST, F_OLD, RHO, RHO_OLD, VEL, VEL_TEMP, VEL_OLD, OBSTACLE, SPONGE, WALL_DIST = Int32.(0:11)
+
+struct LevelHost               # LudwigLevelHost
+    level_id::Int32; n_blocks::Int32; n_owned::Int32; tau::Float32
+    grid_dim_x::Int32; grid_dim_y::Int32; grid_dim_z::Int32
+    block_pointer::Ptr{Int32}; neighbor_table::Ptr{Int32}
+    map_x::Ptr{Int32}; map_y::Ptr{Int32}; map_z::Ptr{Int32}
+    obstacle::Ptr{UInt8}; sponge::Ptr{Float32}; wall_dist::Ptr{Float32}
+    enable_temporal_interpolation::Int32; n_boundary_cells::Int32
+    bouzidi_q_map::Ptr{UInt16}; bouzidi_cell_block::Ptr{Int32}
+    bouzidi_cell_x::Ptr{Int8}; bouzidi_cell_y::Ptr{Int8}; bouzidi_cell_z::Ptr{Int8}
+    comm_boundary::Ptr{UInt8}
+end
+
+struct StepFlags               # LudwigStepFlags
+    domain_nx::Int32; domain_ny::Int32; domain_nz::Int32
+    is_symmetric::Int32; wall_model_active::Int32; use_temporal_interp::Int32; sponge_blend_distributions::Int32
+    c_wale::Float32; nu_sgs_background::Float32; inlet_turbulence::Float32; q_min_threshold::Float32
+end
+
+mutable struct DeviceLevel
+    handle::Ptr{Cvoid}
+    level_id::Int; tau::Float32; n_blocks::Int
+    has_temporal::Bool; bouzidi_enabled::Bool; n_boundary_cells::Int
+end
+
+last_error() = unsafe_string(ccall((:ludwig_last_error, LIB), Cstring, ()))
+check(rc::Cint) = rc == 0 ? nothing : error("libludwig_hip error $rc: $(last_error())")
+
+"""adapt(backend, level) for an MI355X: uploads every array of a host BlockLevel (src/blocks.jl:16-65)."""
+function adapt_level(level, device::Integer = 0)
+    n = length(level.active_block_coords)
+    obstacle_u8 = Array{UInt8}(level.obstacle)
+    GC.@preserve level obstacle_u8 begin
+        h = LevelHost(Int32(level.level_id), Int32(n), Int32(0), level.tau,
+                      Int32(size(level.block_pointer, 1)), Int32(size(level.block_pointer, 2)), Int32(size(level.block_pointer, 3)),
+                      pointer(level.block_pointer), pointer(level.neighbor_table),
+                      pointer(level.map_x), pointer(level.map_y), pointer(level.map_z),
+                      pointer(obstacle_u8), pointer(level.sponge), pointer(level.wall_dist),
+                      Int32(length(level.f_old) > 27), Int32(level.n_boundary_cells),
+                      level.bouzidi_enabled ? Ptr{UInt16}(pointer(level.bouzidi_q_map)) : Ptr{UInt16}(C_NULL),
+                      level.bouzidi_enabled ? pointer(level.bouzidi_cell_block) : Ptr{Int32}(C_NULL),
+                      level.bouzidi_enabled ? pointer(level.bouzidi_cell_x) : Ptr{Int8}(C_NULL),
+                      level.bouzidi_enabled ? pointer(level.bouzidi_cell_y) : Ptr{Int8}(C_NULL),
+                      level.bouzidi_enabled ? pointer(level.bouzidi_cell_z) : Ptr{Int8}(C_NULL),
+                      Ptr{UInt8}(C_NULL))
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ludwig_level_create, LIB), Cint, (Ref{LevelHost}, Cint, Ref{Ptr{Cvoid}}), h, device, out))
+        d = DeviceLevel(out[], level.level_id, level.tau, n, length(level.f_old) > 27, level.bouzidi_enabled, level.n_boundary_cells)
+        for (fld, arr) in ((F, level.f), (F_TEMP, level.f_temp), (RHO, level.rho), (VEL, level.vel), (VEL_TEMP, level.vel_temp))
+            upload!(d, fld, arr)
+        end
+        finalizer(x -> ccall((:ludwig_level_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.handle), d)
+        return d
+    end
+end
+
+upload!(d::DeviceLevel, field::Int32, a::Array) =
+    GC.@preserve a check(ccall((:ludwig_level_upload, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Csize_t), d.handle, field, pointer(a), sizeof(a)))
+
+"""Array(level.field): download into a preallocated host array of the reference's shape."""
+download!(a::Array, d::DeviceLevel, field::Int32) =
+    GC.@preserve a check(ccall((:ludwig_level_download, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Csize_t), d.handle, field, pointer(a), sizeof(a)))
+
+"""init_eq! (src/main.jl:109-134)"""
+init_equilibrium!(d::DeviceLevel) = check(ccall((:ludwig_init_equilibrium, LIB), Cint, (Ptr{Cvoid},), d.handle))
+
+"""
+perform_timestep_v2! (src/physics_v2.jl:26-97). The reference passes f_out/f_in/vel_out/vel_in explicitly; its only callers
+(src/solver_control.jl:35-41) derive them from the parity of `timestep`, which is what the library does. `parent === nothing`
+is level 1, exactly like `parent_f === nothing`.
+"""
+function perform_timestep!(d::DeviceLevel, parent::Union{DeviceLevel,Nothing}, parent_tau::Float32, u_curr::Float32,
+                           flags::StepFlags, timestep::Integer, temporal_weight::Float32)
+    p = parent === nothing ? C_NULL : parent.handle
+    check(ccall((:ludwig_step, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cfloat, Cfloat, Cfloat, Ref{StepFlags}),
+                d.handle, p, Int64(timestep), u_curr, parent_tau, temporal_weight, flags))
+end
+
+"""copy_to_old!(level, f_in, vel_in) for the step `timestep` about to run (src/blocks.jl:199-205)."""
+copy_to_old!(d::DeviceLevel, timestep::Integer) = check(ccall((:ludwig_save_old, LIB), Cint, (Ptr{Cvoid}, Int64), d.handle, Int64(timestep)))
+
+synchronize(d::DeviceLevel) = check(ccall((:ludwig_sync, LIB), Cint, (Ptr{Cvoid},), d.handle))
+
+"""
+recursive_step! with the device calls swapped (src/solver_control.jl:21-143): same order, same parity, same weights.
+"""
+function recursive_step!(grids::Vector{DeviceLevel}, lvl::Int, t_sub::Int, parent, parent_tau::Float32, tw::Float32,
+                         u_vel::Float32, flags::StepFlags)
+    lvl > length(grids) && return
+    level = grids[lvl]
+    has_children = lvl < length(grids)
+    if has_children && flags.use_temporal_interp == 1 && level.has_temporal
+        copy_to_old!(level, t_sub)
+    end
+    perform_timestep!(level, parent, parent_tau, u_vel, flags, t_sub, tw)
+    if has_children
+        recursive_step!(grids, lvl + 1, 2 * t_sub, level, level.tau, 0.0f0, u_vel, flags)
+        recursive_step!(grids, lvl + 1, 2 * t_sub + 1, level, level.tau, 0.5f0, u_vel, flags)
+    end
+end
+
+"""execute_timestep_batch! (src/solver_control.jl:145-165)"""
+function execute_timestep_batch!(grids::Vector{DeviceLevel}, t_start::Int, batch_size::Int, u_curr::Float32, flags::StepFlags)
+    for t_offset in 0:(batch_size - 1)
+        recursive_step!(grids, 1, t_start + t_offset, nothing, 0.5f0, 0.0f0, u_curr, flags)
+    end
+    synchronize(grids[1])
+end
+
+end # module
