@@ -177,6 +177,7 @@ typedef struct LudwigLevelInfo {
     int32_t n_general_blocks;
     int32_t n_boundary_cells;
     int32_t has_temporal_storage, has_post_collision;
+    int32_t n_xrun_blocks;        /* of the fast blocks: how many the current LUDWIG_PART_ALL order steps in x-runs of 4 */
     int64_t device_bytes;
 } LudwigLevelInfo;
 int  ludwig_level_info(const LudwigLevel *level, LudwigLevelInfo *info);

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libludwig_hip.so")
+LIB_PATH = os.environ.get("LUDWIG_HIP_LIB") or os.path.join(_HERE, "csrc", "libludwig_hip.so")   # override: diagnostics only
 
 # enum LudwigField
 F, F_TEMP, F_POST, F_OLD, RHO, RHO_OLD, VEL, VEL_TEMP, VEL_OLD, OBSTACLE, SPONGE, WALL_DIST = range(12)
@@ -65,7 +65,8 @@ class LevelInfo(C.Structure):
     _fields_ = [
         ("n_blocks", C.c_int32), ("n_owned", C.c_int32), ("n_fast_blocks", C.c_int32),
         ("n_general_blocks", C.c_int32), ("n_boundary_cells", C.c_int32),
-        ("has_temporal_storage", C.c_int32), ("has_post_collision", C.c_int32), ("device_bytes", C.c_int64),
+        ("has_temporal_storage", C.c_int32), ("has_post_collision", C.c_int32), ("n_xrun_blocks", C.c_int32),
+        ("device_bytes", C.c_int64),
     ]
 
 

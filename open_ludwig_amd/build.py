@@ -12,8 +12,10 @@ DEPENDS = ["ludwig_hip.hip", "kernels.hpp", "lattice.hpp", os.path.join("..", ".
 OUT = os.path.join(CSRC, "libludwig_hip.so")
 
 # -ffp-contract=off: the reference's CPU path never fuses a*b+c; parity with it is bit-level (DESIGN.md "Numerics").
+# -DLW_NT_STORES: outputs are pure streaming writes (nothing re-reads them inside the launch); non-temporal stores
+# keep them from evicting the face-layer lines neighbouring workgroups still need (2-4 % measured at 256^3).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-               "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+               "-fno-fast-math", "-Wall", "-Wno-unused-function", "-DLW_NT_STORES"]
 
 
 def hipcc_path() -> str:

@@ -229,7 +229,11 @@ __device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off)
 }
 __device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v)
 {
+#ifdef LW_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off));
+#else
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+#endif
 }
 
 // The 27 neighbour block ids of the wave's block, held in SGPRs, regrouped by source z-layer:
@@ -304,87 +308,24 @@ __device__ __forceinline__ void velocity_neighbor(const SCParams &p, const Neigh
     if constexpr (GENERAL) {
         if (blk < 0) off = own_bytes;   // missing neighbour block -> own value
     }
+#ifdef LW_DIAG_NO_VEL_GATHER   // timing-only diagnostic build: results are wrong
+    u1 = __int_as_float(off); u2 = u1 * 2.0f; u3 = u1 * 3.0f;
+#else
     u1 = ld_f32(p.vel_in, off);
     u2 = ld_f32(p.vel_in + p.sk, off);
     u3 = ld_f32(p.vel_in + 2 * p.sk, off);
+#endif
 }
 
-// GENERAL: blocks with a missing neighbour (domain edge / refinement interface); POST: also store f_post_collision
-// (level has Bouzidi cells); WALL: wall model active.
-template <bool GENERAL, bool POST, bool WALL>
-__global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
+// Everything after the loads: moments, obstacle bounce, sponge, wall model, WALE, regularized collision, stores.
+// reference src/physics_kernels.jl:144-354. fs = the 27 pulled populations, u?_? = previous-step velocity of the six
+// face neighbours. Shared by the per-wave kernel and the x-run kernel.
+template <bool POST, bool WALL>
+__device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, const uint32_t own_bytes, float (&fs)[Q],
+                                            const float ux_E, const float uy_E, const float uz_E, const float ux_W, const float uy_W, const float uz_W,
+                                            const float ux_N, const float uy_N, const float uz_N, const float ux_S, const float uy_S, const float uz_S,
+                                            const float ux_T, const float uy_T, const float uz_T, const float ux_B, const float uy_B, const float uz_B)
 {
-    // one work item per WAVE: (block << 3) | z. Which waves share a workgroup / an XCD is the host's choice (order.py).
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = p.items[blockIdx.x * 4 + wave];
-    if (item < 0) return;                                   // padding slot of an XCD-aligned launch order
-    const int b = item >> 3;
-    const int z = item & 7;                                 // wave-uniform z-plane, 0-based
-    const int lane = threadIdx.x & 63;
-    LanePos l;
-    l.x = lane & 7; l.y = lane >> 3;
-    l.x0 = l.x == 0; l.x7 = l.x == 7; l.y0 = l.y == 0; l.y7 = l.y == 7;
-    const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
-    const int flags = meta[NBR_FLAGS];
-    const NeighbourIds nbr = load_neighbour_ids(meta, z);
-    const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
-
-    // ---- pull-stream, reference src/physics_kernels.jl:62-149 ----
-    float fs[Q];
-    static_for<0, Q>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
-        const int sel = source_block<k>(nbr, l);
-        const uint32_t off = (uint32_t)sel * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
-        const float *fk = p.f_in + p.sk * k;
-        if constexpr (!GENERAL) {
-            fs[k] = ld_f32(fk, off);
-        } else {
-            float val;
-            if (sel >= 0) {
-                val = ld_f32(fk, off);
-            } else {
-                // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
-                const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
-                const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
-                const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
-                const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
-                const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
-                if (is_inlet) {
-                    const float noise = p.inlet_turbulence > 0.0f
-                                            ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
-                                            : 0.0f;
-                    const float u_inst = p.u_inlet + noise;
-                    const float cu_in = (float)cx * u_inst;
-                    val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
-                } else if (is_outlet) {
-                    const float cu_out = (float)cx * p.u_inlet;
-                    val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
-                } else if (is_y_min && p.is_symmetric == 1) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
-                } else if (is_y_min || is_y_max) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
-                } else if (is_z_min || is_z_max) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
-                } else if (p.is_level_1 == 0) {
-                    val = interpolate_with_rescaling(p, src_gx, src_gy, src_gz, k, WEIGHT(k), (float)cx, (float)cy, (float)cz);
-                } else {
-                    val = WEIGHT(k);
-                }
-            }
-            fs[k] = val;
-        }
-    });
-    // previous-step velocity of the 6 face neighbours (WALE stencil) - issued with the pulls so that all loads of the
-    // wave are in flight together; reference src/physics_utils.jl:72-83
-    float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
-    velocity_neighbor<1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_E, uy_E, uz_E);
-    velocity_neighbor<-1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_W, uy_W, uz_W);
-    velocity_neighbor<0, 1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_N, uy_N, uz_N);
-    velocity_neighbor<0, -1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_S, uy_S, uz_S);
-    velocity_neighbor<0, 0, 1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_T, uy_T, uz_T);
-    velocity_neighbor<0, 0, -1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_B, uy_B, uz_B);
-
     // moments in the reference's order: rho += f_k; j += f_k * c_k for k = 1..27
     float rho = 0.0f, jx = 0.0f, jy = 0.0f, jz = 0.0f;
     static_for<0, Q>([&](auto kc) {
@@ -534,6 +475,222 @@ __global__ __launch_bounds__(256) void k_stream_collide(const SCParams p)
         if constexpr (POST) st_f32(p.f_post + p.sk * k, own_bytes, f_coll);
         st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
     });
+}
+
+// GENERAL: blocks with a missing neighbour (domain edge / refinement interface); POST: also store f_post_collision
+// (level has Bouzidi cells); WALL: wall model active.
+#ifndef LW_WAVES_PER_EU
+#define LW_WAVES_ATTR
+#else
+#define LW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LW_WAVES_PER_EU, LW_WAVES_PER_EU)))
+#endif
+template <bool GENERAL, bool POST, bool WALL>
+__global__ __launch_bounds__(256) LW_WAVES_ATTR void k_stream_collide(const SCParams p)
+{
+    // one work item per WAVE: (block << 3) | z. Which waves share a workgroup / an XCD is the host's choice (order.py).
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = p.items[blockIdx.x * 4 + wave];
+    if (item < 0) return;                                   // padding slot of an XCD-aligned launch order
+    const int b = item >> 3;
+    const int z = item & 7;                                 // wave-uniform z-plane, 0-based
+    const int lane = threadIdx.x & 63;
+    LanePos l;
+    l.x = lane & 7; l.y = lane >> 3;
+    l.x0 = l.x == 0; l.x7 = l.x == 7; l.y0 = l.y == 0; l.y7 = l.y == 7;
+    const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
+    const int flags = meta[NBR_FLAGS];
+    const NeighbourIds nbr = load_neighbour_ids(meta, z);
+    const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
+
+    // ---- pull-stream, reference src/physics_kernels.jl:62-149 ----
+    float fs[Q];
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+        const int sel = source_block<k>(nbr, l);
+        const uint32_t off = (uint32_t)sel * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
+        const float *fk = p.f_in + p.sk * k;
+        if constexpr (!GENERAL) {
+            fs[k] = ld_f32(fk, off);
+        } else {
+            float val;
+            if (sel >= 0) {
+                val = ld_f32(fk, off);
+            } else {
+                // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
+                const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
+                const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
+                const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
+                const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
+                const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
+                if (is_inlet) {
+                    const float noise = p.inlet_turbulence > 0.0f
+                                            ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
+                                            : 0.0f;
+                    const float u_inst = p.u_inlet + noise;
+                    const float cu_in = (float)cx * u_inst;
+                    val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
+                } else if (is_outlet) {
+                    const float cu_out = (float)cx * p.u_inlet;
+                    val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
+                } else if (is_y_min && p.is_symmetric == 1) {
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                } else if (is_y_min || is_y_max) {
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                } else if (is_z_min || is_z_max) {
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
+                } else if (p.is_level_1 == 0) {
+                    val = interpolate_with_rescaling(p, src_gx, src_gy, src_gz, k, WEIGHT(k), (float)cx, (float)cy, (float)cz);
+                } else {
+                    val = WEIGHT(k);
+                }
+            }
+            fs[k] = val;
+        }
+    });
+    // previous-step velocity of the 6 face neighbours (WALE stencil) - issued with the pulls so that all loads of the
+    // wave are in flight together; reference src/physics_utils.jl:72-83
+    float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
+    velocity_neighbor<1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_E, uy_E, uz_E);
+    velocity_neighbor<-1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_W, uy_W, uz_W);
+    velocity_neighbor<0, 1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_N, uy_N, uz_N);
+    velocity_neighbor<0, -1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_S, uy_S, uz_S);
+    velocity_neighbor<0, 0, 1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_T, uy_T, uz_T);
+    velocity_neighbor<0, 0, -1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_B, uy_B, uz_B);
+
+    finish_cell<POST, WALL>(p, flags, own_bytes, fs, ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S,
+                            ux_T, uy_T, uz_T, ux_B, uy_B, uz_B);
+}
+
+// ---- x-run variant of the all-neighbours kernel ------------------------------------------------------------
+// Workgroup = the SAME z-plane of NW x-consecutive blocks (host guarantees: items 0..NW-1 of the group are valid,
+// share z, item i+1 is the +x neighbour of item i, all blocks have their 26 neighbours). Every global access is an
+// aligned 256-B plane row set (x unshifted; the y / z shift only changes the row / plane, i.e. stays 16-B aligned);
+// the +-1 shift in x is a DPP lane shift, and the face column each block needs from its x neighbour is handed over
+// between neighbouring waves through 24 x 8 floats of LDS. Only the two outer faces of the run are still read as
+// strided columns from global memory. Measured motivation: DESIGN.md section 3.1 (the x-face column and the 4-byte
+// misalignment are what separate the pull from an aligned copy on MI355X).
+__device__ __forceinline__ float dpp_from_lower_lane(float v)   // lane i <- lane i-1 inside 16-lane rows (row_shr:1)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x111, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_from_upper_lane(float v)   // lane i <- lane i+1 inside 16-lane rows (row_shl:1)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x101, 0xF, 0xF, false));
+}
+// slot of population k in the exchange buffer: cx=+1 populations publish their x=7 column in slots 0..8,
+// cx=-1 populations their x=0 column in slots 9..17 (k = (cx+1) + 3 j, j = 0..8)
+__host__ __device__ constexpr int XSLOT(int k) { return CX(k) == 1 ? k / 3 : 9 + k / 3; }
+
+template <int NW, bool POST, bool WALL>
+__global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams p)
+{
+    __shared__ float xch[NW][24][8];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = p.items[blockIdx.x * NW + wave];
+    const int b = item >> 3;
+    const int z = item & 7;
+    const int lane = threadIdx.x & 63;
+    LanePos l;
+    l.x = lane & 7; l.y = lane >> 3;
+    l.x0 = l.x == 0; l.x7 = l.x == 7; l.y0 = l.y == 0; l.y7 = l.y == 7;
+    const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
+    const int flags = meta[NBR_FLAGS];
+    const NeighbourIds nbr = load_neighbour_ids(meta, z);
+    const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
+    const bool first = wave == 0, last = wave == NW - 1;      // wave-uniform
+
+    // ---- aligned loads: value of population k at (x, y - cy, z - cz) ----
+    float fs[Q];
+    float halo[Q];                                            // outer-face column (first / last wave only)
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), g = 1 - CZ(k);
+        const bool yo = cy == 1 ? l.y0 : (cy == -1 ? l.y7 : false);
+        const int c00 = nbr.id[g][4], cY = nbr.id[g][4 - 3 * cy];
+        const int sel = cy != 0 ? (yo ? cY : c00) : c00;
+        const uint32_t rowz = (uint32_t)((8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(nbr.zs[g] * 256);
+        const float *fk = p.f_in + p.sk * k;
+        fs[k] = ld_f32(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
+        halo[k] = 0.0f;
+        if constexpr (cx != 0) {
+            if (cx == 1 ? first : last) {                     // the run's outer face: strided column of the x / xy neighbour
+                const int cX = nbr.id[g][4 - cx], cXY = nbr.id[g][4 - cx - 3 * cy];
+                const int selx = cy != 0 ? (yo ? cXY : cX) : cX;
+                if (cx == 1 ? l.x0 : l.x7)
+                    halo[k] = ld_f32(fk, (uint32_t)selx * (CELLS * 4) + rowz + (uint32_t)((cx == 1 ? 7 : 0) * 4));
+            }
+        }
+    });
+    // previous-step velocity: centre plane, planes z+-1 (aligned), y-face rows and outer x-face columns (masked)
+    float uc[3], uT[3], uB[3], uy_edge[3], ux_edge_lo[3], ux_edge_hi[3];
+    {
+        const int bT = z == 7 ? nbr.id[2][4] : b, bB = z == 0 ? nbr.id[0][4] : b;
+        const uint32_t xy = (uint32_t)((l.x + 8 * l.y) * 4);
+        const uint32_t offT = (uint32_t)bT * (CELLS * 4) + xy + (uint32_t)(((z + 1) & 7) * 256);
+        const uint32_t offB = (uint32_t)bB * (CELLS * 4) + xy + (uint32_t)(((z - 1) & 7) * 256);
+        // lanes y==0 fetch row 7 of the -y neighbour, lanes y==7 row 0 of the +y neighbour (one masked load per component)
+        const int by_ = l.y0 ? nbr.id[1][4 - 3] : nbr.id[1][4 + 3];
+        const uint32_t offY = (uint32_t)by_ * (CELLS * 4) + (uint32_t)((l.x + 8 * (l.y0 ? 7 : 0) + 64 * z) * 4);
+        const uint32_t offXlo = (uint32_t)nbr.id[1][4 - 1] * (CELLS * 4) + (uint32_t)((7 + 8 * l.y + 64 * z) * 4);
+        const uint32_t offXhi = (uint32_t)nbr.id[1][4 + 1] * (CELLS * 4) + (uint32_t)((0 + 8 * l.y + 64 * z) * 4);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *vc = p.vel_in + p.sk * c;
+            uc[c] = ld_f32(vc, own_bytes);
+            uT[c] = ld_f32(vc, offT);
+            uB[c] = ld_f32(vc, offB);
+            uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
+            if (l.y0 || l.y7) uy_edge[c] = ld_f32(vc, offY);
+            if (first) { if (l.x0) ux_edge_lo[c] = ld_f32(vc, offXlo); }
+            if (last) { if (l.x7) ux_edge_hi[c] = ld_f32(vc, offXhi); }
+        }
+    }
+
+    // ---- publish the face columns the neighbouring waves need ----
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k);
+        if constexpr (cx == 1) { if (l.x7) xch[wave][XSLOT(k)][l.y] = fs[k]; }
+        if constexpr (cx == -1) { if (l.x0) xch[wave][XSLOT(k)][l.y] = fs[k]; }
+    });
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (l.x7) xch[wave][18 + c][l.y] = uc[c];
+        if (l.x0) xch[wave][21 + c][l.y] = uc[c];
+    }
+    __syncthreads();
+    const int wlo = first ? 0 : wave - 1, whi = last ? NW - 1 : wave + 1;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k);
+        if constexpr (cx == 1) {
+            const float inner = dpp_from_lower_lane(fs[k]);
+            const float edge = first ? halo[k] : xch[wlo][XSLOT(k)][l.y];
+            fs[k] = l.x0 ? edge : inner;
+        }
+        if constexpr (cx == -1) {
+            const float inner = dpp_from_upper_lane(fs[k]);
+            const float edge = last ? halo[k] : xch[whi][XSLOT(k)][l.y];
+            fs[k] = l.x7 ? edge : inner;
+        }
+    });
+    float uE[3], uW[3], uN[3], uS[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float e_edge = last ? ux_edge_hi[c] : xch[whi][21 + c][l.y];
+        const float w_edge = first ? ux_edge_lo[c] : xch[wlo][18 + c][l.y];
+        // cross-lane reads must execute with ALL lanes active: never inside an arm of ?: (that arm runs under a
+        // reduced EXEC mask and a DPP read of an inactive lane silently keeps the old value)
+        const float e_in = dpp_from_upper_lane(uc[c]), w_in = dpp_from_lower_lane(uc[c]);
+        uE[c] = l.x7 ? e_edge : e_in;
+        uW[c] = l.x0 ? w_edge : w_in;
+        const float n_in = __shfl_down(uc[c], 8, 64), s_in = __shfl_up(uc[c], 8, 64);
+        uN[c] = l.y7 ? uy_edge[c] : n_in;
+        uS[c] = l.y0 ? uy_edge[c] : s_in;
+    }
+    finish_cell<POST, WALL>(p, flags, own_bytes, fs, uE[0], uE[1], uE[2], uW[0], uW[1], uW[2], uN[0], uN[1], uN[2], uS[0], uS[1], uS[2],
+                            uT[0], uT[1], uT[2], uB[0], uB[1], uB[2]);
 }
 
 // ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----

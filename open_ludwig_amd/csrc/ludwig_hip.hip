@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -36,7 +37,8 @@ int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(LUDWIG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int N_PARTS = 3, N_CLASSES = 2;   // class 0 = all-neighbours-present kernel, 1 = general kernel
+constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 0 = all-neighbours kernel, 1 = general kernel, 2 = x-run kernel
+constexpr int XRUN = 4;                     // waves (= x-consecutive blocks) per x-run workgroup
 
 }  // namespace
 
@@ -154,14 +156,36 @@ bool block_in_part(const LudwigLevel *L, int b, int part)
 int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
 {
     // one item per wave: (block << 3) | z, or -1 = idle wave. 4 consecutive items form one 256-thread workgroup.
+    // A workgroup whose 4 items are the same plane of 4 x-consecutive all-neighbour blocks goes to the x-run kernel
+    // (class 2); everything else is stepped wave by wave (class 0 / 1).
     std::vector<int32_t> cls[N_CLASSES];
+    auto is_fast = [&](int b) { return (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0; };
     for (int64_t i = 0; i < n; ++i) {
-        if (items[i] < 0) { cls[0].push_back(-1); continue; }   // idle slot: keeps the slot -> XCD alignment of class 0
-        const int b = items[i] >> 3;
-        if (b < 0 || b >= L->n_owned) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not an owned block", (long long)i, b);
-        if (!block_in_part(L, b, part)) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not in part %d", (long long)i, b, part);
-        const bool fast = (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0;
-        cls[fast ? 0 : 1].push_back(items[i]);
+        if (items[i] >= 0) {
+            const int b = items[i] >> 3;
+            if (b < 0 || b >= L->n_owned) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not an owned block", (long long)i, b);
+            if (!block_in_part(L, b, part)) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not in part %d", (long long)i, b, part);
+        }
+    }
+    const bool use_xrun = getenv("LUDWIG_NO_XRUN") == nullptr;
+    for (int64_t g = 0; g < n; g += XRUN) {
+        const int64_t m = std::min<int64_t>(XRUN, n - g);
+        bool run = use_xrun && m == XRUN;
+        for (int64_t w = 0; run && w < m; ++w) {
+            const int32_t it = items[g + w];
+            if (it < 0 || !is_fast(it >> 3) || (it & 7) != (items[g] & 7)) run = false;
+            else if (w > 0 && L->h_meta[(size_t)(items[g + w - 1] >> 3) * NBR_STRIDE + DIR(1, 0, 0)] != (it >> 3)) run = false;
+        }
+        if (run) {
+            for (int64_t w = 0; w < m; ++w) cls[2].push_back(items[g + w]);
+            for (int64_t w = 0; w < m; ++w) cls[0].push_back(-1);   // keep class 0's slot -> XCD alignment
+        } else {
+            for (int64_t w = 0; w < m; ++w) {
+                const int32_t it = items[g + w];
+                if (it < 0) cls[0].push_back(-1);
+                else cls[is_fast(it >> 3) ? 0 : 1].push_back(it);
+            }
+        }
     }
     for (int c = 0; c < N_CLASSES; ++c) {
         bool any = false;
@@ -178,39 +202,69 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
     return LUDWIG_OK;
 }
 
-// Default launch order ("plane-per-XCD").
+// Default launch order: x-runs, plane-per-XCD.
 // A cache line of population k, z-plane p of a block is read only by waves working on plane p + cz(k): in the
-// owning block and in its x/y neighbours (faces, edges). Nothing is shared across different plane indices.
-// MI355X deals workgroup g to XCD g % 8, each XCD with a private L2, so we give in-block plane z to XCD z:
-// every line is then fetched by exactly one XCD, and the neighbours that re-read it sit in the same workgroup
-// (the same plane of 4 y-adjacent blocks = 4 waves) or in a workgroup the same XCD runs next (patches are swept
-// y-fastest, then x, then block-z). Measured on MI355X at 256^3 against 8 other orders (tools/order_sweep.py,
-// DESIGN.md "Launch order"): L2 read misses 226 -> 168 B/cell, 4-9 % less time than block-by-block order.
+// owning block and in its x/y neighbours (faces, edges); nothing is shared across different plane indices.
+//  * workgroup = the same plane of 4 x-consecutive all-neighbour blocks -> the x-run kernel: aligned loads only,
+//    x-face columns handed over in LDS (kernels.hpp). Runs are cut greedily along every (by,bz) row of blocks.
+//  * MI355X deals workgroup g to XCD g % 8 (private L2 each): slot g = 8 * group + z puts plane z on XCD z, so a
+//    line is fetched by one XCD only; groups are swept bz-fastest (adjacent memory), then along x, then y.
+//  * blocks that do not fit a run (domain edges, refinement interfaces, leftovers) are stepped wave by wave,
+//    four blocks per workgroup, same slot rule.
+// Measured at 256^3 against the alternatives with tools/order_sweep.py (DESIGN.md "Launch order").
 int default_items(LudwigLevel *L, int part)
 {
-    struct Key { int32_t bz, bx, py, by, b; };
-    std::vector<Key> keys;
+    struct Blk { int32_t bx, by, bz, b; };
+    std::vector<Blk> blks;
     for (int b = 0; b < L->n_owned; ++b) {
         if (!block_in_part(L, b, part)) continue;
         const int32_t *row = &L->h_meta[(size_t)b * NBR_STRIDE];
-        keys.push_back({row[NBR_BZ], row[NBR_BX], (row[NBR_BY] - 1) >> 2, row[NBR_BY], b});
+        blks.push_back({row[NBR_BX], row[NBR_BY], row[NBR_BZ], b});
     }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &c) {
+    std::sort(blks.begin(), blks.end(), [](const Blk &a, const Blk &c) {
+        if (a.by != c.by) return a.by < c.by;
         if (a.bz != c.bz) return a.bz < c.bz;
-        if (a.bx != c.bx) return a.bx < c.bx;
-        if (a.py != c.py) return a.py < c.py;
-        return a.by < c.by;
+        return a.bx < c.bx;
     });
-    // patches of up to 4 y-adjacent blocks; workgroup slot g = 8 * patch + z  (-> XCD z)
-    std::vector<int32_t> seq;
+    auto fast = [&](int b) { return (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0; };
+    struct Group { int32_t by, bx0, bz; int32_t b[XRUN]; };
+    std::vector<Group> runs;
+    std::vector<Blk> singles;
     size_t i = 0;
-    while (i < keys.size()) {
+    while (i < blks.size()) {
+        // maximal chain of x-consecutive fast blocks starting at i (same by,bz row)
         size_t j = i;
-        while (j < keys.size() && j - i < 4 && keys[j].bz == keys[i].bz && keys[j].bx == keys[i].bx && keys[j].py == keys[i].py) ++j;
-        for (int z = 0; z < 8; ++z)
-            for (size_t w = 0; w < 4; ++w) seq.push_back(i + w < j ? (keys[i + w].b << 3) | z : -1);
-        i = j;
+        if (fast(blks[i].b)) {
+            while (j + 1 < blks.size() && blks[j + 1].by == blks[i].by && blks[j + 1].bz == blks[i].bz && fast(blks[j + 1].b) &&
+                   L->h_meta[(size_t)blks[j].b * NBR_STRIDE + DIR(1, 0, 0)] == blks[j + 1].b)
+                ++j;
+        }
+        size_t k = i;
+        for (; k + XRUN <= j + 1; k += XRUN) {
+            Group g{blks[k].by, blks[k].bx, blks[k].bz, {}};
+            for (int w = 0; w < XRUN; ++w) g.b[w] = blks[k + w].b;
+            runs.push_back(g);
+        }
+        for (; k <= j; ++k) singles.push_back(blks[k]);
+        i = j + 1;
     }
+    std::sort(runs.begin(), runs.end(), [](const Group &a, const Group &c) {
+        if (a.by != c.by) return a.by < c.by;
+        if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
+        return a.bz < c.bz;
+    });
+    std::sort(singles.begin(), singles.end(), [](const Blk &a, const Blk &c) {
+        if (a.by != c.by) return a.by < c.by;
+        if (a.bx != c.bx) return a.bx < c.bx;
+        return a.bz < c.bz;
+    });
+    std::vector<int32_t> seq;
+    for (const Group &g : runs)
+        for (int z = 0; z < 8; ++z)
+            for (int w = 0; w < XRUN; ++w) seq.push_back((g.b[w] << 3) | z);
+    for (size_t s0 = 0; s0 < singles.size(); s0 += 4)
+        for (int z = 0; z < 8; ++z)
+            for (size_t w = 0; w < 4; ++w) seq.push_back(s0 + w < singles.size() ? (singles[s0 + w].b << 3) | z : -1);
     return set_items(L, part, seq.data(), (int64_t)seq.size());
 }
 
@@ -275,13 +329,18 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.items = L->items[part][c];
         const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
 #define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, L->stream, p)
+#define LW_LAUNCH_X(P, W) hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, P, W>), dim3((unsigned)(L->n_items[part][c] / XRUN)), dim3(64 * XRUN), 0, L->stream, p)
         if (c == 0) {
             if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
             else      { if (wall) LW_LAUNCH(false, false, true); else LW_LAUNCH(false, false, false); }
-        } else {
+        } else if (c == 1) {
             if (post) { if (wall) LW_LAUNCH(true, true, true); else LW_LAUNCH(true, true, false); }
             else      { if (wall) LW_LAUNCH(true, false, true); else LW_LAUNCH(true, false, false); }
+        } else {
+            if (post) { if (wall) LW_LAUNCH_X(true, true); else LW_LAUNCH_X(true, false); }
+            else      { if (wall) LW_LAUNCH_X(false, true); else LW_LAUNCH_X(false, false); }
         }
+#undef LW_LAUNCH_X
 #undef LW_LAUNCH
         LW_HIP(hipGetLastError());
     }
@@ -630,6 +689,7 @@ int ludwig_level_info(const LudwigLevel *L, LudwigLevelInfo *info)
     info->n_boundary_cells = L->n_bc;
     info->has_temporal_storage = L->has_temporal;
     info->has_post_collision = L->has_post;
+    info->n_xrun_blocks = (int32_t)(L->n_items[LUDWIG_PART_ALL][2] / 8);
     info->device_bytes = L->device_bytes;
     return LUDWIG_OK;
 }

@@ -97,6 +97,10 @@ BUILDERS = {
     "pxcd_8x8_xyz": lambda c: plane_per_xcd(c, 8, 8, "xyz"),
     "pxcd_4x4_zxy": lambda c: plane_per_xcd(c, 4, 4, "zxy"),
     "prr_2x2_xyz": lambda c: plane_round_robin(c, 2, 2, "xyz"),
+    "prr_4x1_xyz": lambda c: plane_round_robin(c, 4, 1, "xyz"),
+    "prr_4x1_zxy": lambda c: plane_round_robin(c, 4, 1, "zxy"),
+    "pxcd_4x1_zxy": lambda c: plane_per_xcd(c, 4, 1, "zxy"),
+    "pxcd_4x1_xzy": lambda c: plane_per_xcd(c, 4, 1, "xzy"),
     "cols_xinner": lambda c: columns(c, 1 << 20, 1),
     "cols_t44": lambda c: columns(c, 4, 4),
     "cols_t22": lambda c: columns(c, 2, 2),

@@ -59,6 +59,43 @@ def test_periodic_box_bit_exact(gpu, nb, steps):
     compare(grids, dev, steps)
 
 
+@pytest.mark.parametrize("nb", [(4, 4, 4), (8, 2, 3), (12, 2, 2), (5, 3, 2), (3, 2, 2)])
+def test_periodic_box_rough_state_bit_exact(gpu, nb):
+    """Non-smooth random state: every lane sees distinct values, so a wrong cross-lane move (DPP / shuffle / LDS
+    column exchange of the x-run kernel) cannot hide. Widths 4, 8, 12 = whole x-runs; 5 and 3 leave wave-by-wave blocks."""
+    grids, params = cases.periodic_box(nb)
+    cases.init_perturbed(grids[0], 5)
+    dev = run_both(grids, params, 3, 0.0)
+    info = dev[0].info()
+    assert info.n_xrun_blocks == (nb[0] // 4) * 4 * nb[1] * nb[2]
+    compare(grids, dev, 3)
+
+
+@pytest.mark.parametrize("order_name", ["block_planes", "pxcd_4x1_zxy", "prr_4x1_xyz", "pxcd_2x2_xyz", "cols_t44"])
+def test_result_does_not_depend_on_launch_order(gpu, order_name):
+    from open_ludwig_amd import order as order_mod
+    grids, params = cases.periodic_box((8, 3, 2))
+    cases.init_perturbed(grids[0], 9)
+    dev = [adapt(g, 0) for g in grids]
+    dev[0].set_order(order_mod.build(order_name, np.asarray(grids[0].active_block_coords)))
+    execute_timestep_batch(dev, 1, 4, np.float32(0.0), params)
+    oracle.execute_timestep_batch(grids, 1, 4, np.float32(0.0), params)
+    compare(grids, dev, 4)
+
+
+def test_tunnel_interior_uses_x_runs(gpu):
+    """A tunnel long enough that interior all-neighbour blocks form x-runs: the x-run kernel then runs with obstacle,
+    sponge, Bouzidi (POST) and wall-model (WALL) work inside it."""
+    grids, params = cases.tunnel_with_sphere((8, 4, 4), levels=1, wall_model=False)
+    dev = run_both(grids, params, 3, 0.05)
+    assert dev[0].info().n_xrun_blocks >= 16
+    compare(grids, dev, 3)
+    grids, params = cases.tunnel_with_sphere((8, 4, 4), levels=1, wall_model=True, tau=0.5003)
+    dev = run_both(grids, params, 3, 0.05)
+    assert dev[0].info().n_xrun_blocks >= 16
+    compare(grids, dev, 3, exact=False)
+
+
 def test_periodic_box_bgk_only(gpu):
     """BASELINE configs[0] "BGK only": c_wale = 0 and nu_sgs_background = 0 (regularisation cannot be disabled, F9)."""
     grids, params = cases.periodic_box((4, 4, 4))
