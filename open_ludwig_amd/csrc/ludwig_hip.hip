@@ -207,8 +207,8 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
 // owning block and in its x/y neighbours (faces, edges); nothing is shared across different plane indices.
 //  * workgroup = the same plane of 4 x-consecutive all-neighbour blocks -> the x-run kernel: aligned loads only,
 //    x-face columns handed over in LDS (kernels.hpp). Runs are cut greedily along every (by,bz) row of blocks.
-//  * MI355X deals workgroup g to XCD g % 8 (private L2 each): slot g = 8 * group + z puts plane z on XCD z, so a
-//    line is fetched by one XCD only; groups are swept bz-fastest (adjacent memory), then along x, then y.
+//  * MI355X deals workgroup g to XCD g % 8 (private L2 each): the 8 planes of a group occupy 8 consecutive slots,
+//    plane z on XCD (z + bz) % 8, so a line is fetched by one XCD only; groups are swept y-fastest, then x, then z.
 //  * blocks that do not fit a run (domain edges, refinement interfaces, leftovers) are stepped wave by wave,
 //    four blocks per workgroup, same slot rule.
 // Measured at 256^3 against the alternatives with tools/order_sweep.py (DESIGN.md "Launch order").
@@ -248,23 +248,30 @@ int default_items(LudwigLevel *L, int part)
         for (; k <= j; ++k) singles.push_back(blks[k]);
         i = j + 1;
     }
+    // sweep: y fastest (y-neighbour groups re-read each other's face rows: next workgroup on the same XCD), then x, then z
     std::sort(runs.begin(), runs.end(), [](const Group &a, const Group &c) {
-        if (a.by != c.by) return a.by < c.by;
+        if (a.bz != c.bz) return a.bz < c.bz;
         if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
-        return a.bz < c.bz;
+        return a.by < c.by;
     });
     std::sort(singles.begin(), singles.end(), [](const Blk &a, const Blk &c) {
-        if (a.by != c.by) return a.by < c.by;
+        if (a.bz != c.bz) return a.bz < c.bz;
         if (a.bx != c.bx) return a.bx < c.bx;
-        return a.bz < c.bz;
+        return a.by < c.by;
     });
+    // slot 8 * group + x runs on XCD x and steps plane z = (x - bz) mod 8: x/y neighbours (same bz, same plane) share an
+    // XCD, and over bz every XCD sees every plane index, i.e. every value of address bits 8..10 (no L2-channel aliasing)
     std::vector<int32_t> seq;
     for (const Group &g : runs)
-        for (int z = 0; z < 8; ++z)
+        for (int x = 0; x < 8; ++x) {
+            const int z = ((x - g.bz) % 8 + 8) % 8;
             for (int w = 0; w < XRUN; ++w) seq.push_back((g.b[w] << 3) | z);
+        }
     for (size_t s0 = 0; s0 < singles.size(); s0 += 4)
-        for (int z = 0; z < 8; ++z)
+        for (int x = 0; x < 8; ++x) {
+            const int z = ((x - singles[s0].bz) % 8 + 8) % 8;
             for (size_t w = 0; w < 4; ++w) seq.push_back(s0 + w < singles.size() ? (singles[s0 + w].b << 3) | z : -1);
+        }
     return set_items(L, part, seq.data(), (int64_t)seq.size());
 }
 

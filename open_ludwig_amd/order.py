@@ -44,7 +44,8 @@ def _patches(coords, px: int, py: int, sweep: str):
     """group blocks into px x py patches in (bx,by) at equal bz; returns list of arrays of block ids, in sweep order"""
     c = np.asarray(coords).astype(np.int64) - 1
     kx, ky, kz = c[:, 0] // px, c[:, 1] // py, c[:, 2]
-    key = {"xyz": (kx, ky, kz), "xzy": (kx, kz, ky), "zxy": (kz, kx, ky), "yxz": (ky, kx, kz)}[sweep]   # fastest first
+    key = {"xyz": (kx, ky, kz), "xzy": (kx, kz, ky), "zxy": (kz, kx, ky), "yxz": (ky, kx, kz), "yzx": (ky, kz, kx),
+           "zyx": (kz, ky, kx)}[sweep]   # fastest first
     order = np.lexsort((c[:, 0], c[:, 1]) + key)
     ks = np.stack([kx, ky, kz], 1)[order]
     cut = np.flatnonzero(np.r_[True, (ks[1:] != ks[:-1]).any(1), True])
@@ -60,6 +61,20 @@ def plane_per_xcd(coords, px: int = 2, py: int = 2, sweep: str = "xyz") -> np.nd
             items = _pad4((int(b) << 3) | z for b in blocks)
             for i in range(0, len(items), WAVES):
                 seqs[z].append(items[i:i + WAVES])
+    return _per_xcd(seqs)
+
+
+def plane_per_xcd_rot(coords, px: int = 4, py: int = 1, sweep: str = "zxy", rot: str = "bz") -> np.ndarray:
+    """as plane_per_xcd, but plane z of a patch at block-z bz goes to XCD (z + bz) % 8: x/y neighbours (same bz, same
+    plane) still meet on one XCD, while every XCD now sees every plane index, i.e. all address bits 8..10"""
+    c = np.asarray(coords).astype(np.int64) - 1
+    seqs = [[] for _ in range(N_XCD)]
+    for blocks in _patches(coords, px, py, sweep):
+        r = int(c[blocks[0], 2]) if rot == "bz" else int(c[blocks[0], 2] + c[blocks[0], 1])
+        for z in range(8):
+            items = _pad4((int(b) << 3) | z for b in blocks)
+            for i in range(0, len(items), WAVES):
+                seqs[(z + r) % N_XCD].append(items[i:i + WAVES])
     return _per_xcd(seqs)
 
 
@@ -98,6 +113,16 @@ BUILDERS = {
     "pxcd_4x4_zxy": lambda c: plane_per_xcd(c, 4, 4, "zxy"),
     "prr_2x2_xyz": lambda c: plane_round_robin(c, 2, 2, "xyz"),
     "prr_4x1_xyz": lambda c: plane_round_robin(c, 4, 1, "xyz"),
+    "pxcdrot_4x1_zxy": lambda c: plane_per_xcd_rot(c, 4, 1, "zxy", "bz"),
+    "pxcdrot_4x1_xzy": lambda c: plane_per_xcd_rot(c, 4, 1, "xzy", "bz"),
+    "pxcdrot_4x1_xyz": lambda c: plane_per_xcd_rot(c, 4, 1, "xyz", "bz"),
+    "pxcdrot2_4x1_zxy": lambda c: plane_per_xcd_rot(c, 4, 1, "zxy", "bzy"),
+    "pxcd_4x1_yxz": lambda c: plane_per_xcd(c, 4, 1, "yxz"),
+    "pxcd_4x1_yzx": lambda c: plane_per_xcd(c, 4, 1, "yzx"),
+    "pxcd_4x1_zyx": lambda c: plane_per_xcd(c, 4, 1, "zyx"),
+    "pxcdrot_4x1_yxz": lambda c: plane_per_xcd_rot(c, 4, 1, "yxz", "bz"),
+    "pxcdrot_4x1_yzx": lambda c: plane_per_xcd_rot(c, 4, 1, "yzx", "bz"),
+    "pxcdrot_4x1_zyx": lambda c: plane_per_xcd_rot(c, 4, 1, "zyx", "bz"),
     "prr_4x1_zxy": lambda c: plane_round_robin(c, 4, 1, "zxy"),
     "pxcd_4x1_zxy": lambda c: plane_per_xcd(c, 4, 1, "zxy"),
     "pxcd_4x1_xzy": lambda c: plane_per_xcd(c, 4, 1, "xzy"),
