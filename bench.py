@@ -86,6 +86,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearsal = bool(os.environ.get("LUDWIG_BENCH_FORCE_DEVICE"))   # N > 1 on a 1-GPU box: gloo + host-staged messages
+    if rehearsal:
+        local_rank = int(os.environ["LUDWIG_BENCH_FORCE_DEVICE"])
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -95,7 +98,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")       # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     nb = args.size // 8
     cells_per_rank = (nb * 8) ** 3
@@ -116,7 +122,8 @@ def main():
     else:
         from open_ludwig_amd import partition
         runner = partition.periodic_weak_scaling_box(rank, world, (nb, nb, nb), device=local_rank,
-                                                      overlap=not args.no_overlap, order=args.order)
+                                                      overlap=not args.no_overlap, order=args.order,
+                                                      stage_through_host=rehearsal)
         level = runner.level
 
         def step(t):
@@ -143,12 +150,10 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     if dist is not None:
-        w = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)
-        wall = float(w.item())
-        k = torch.tensor([kern_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kern_ms = float(k.item())
+        red_dev = "cpu" if rehearsal else "cuda"
+        w = torch.tensor([wall, kern_ms], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)      # slowest rank defines the step time
+        wall, kern_ms = float(w[0].item()), float(w[1].item())
 
     # sanity: the state must still be finite and the flow non-trivial (no skipped work)
     rho = level.download("rho")
@@ -177,11 +182,12 @@ def main():
                                    f"Taylor-Green start (SURVEY 8d C2)" + ("" if world == 1 else f"; {world} bricks, one-cell halo of f,u per step over RCCL"),
                        "cells_per_gpu": cells_per_rank, "global_cells": total_cells, "tau": 0.5006, "c_wale": 0.5,
                        "nu_sgs_background": 0.0005, "launch_order": args.order or "library default",
-                       "parallelism": "single GPU" if world == 1 else f"spatial domain decomposition x{world}",
+                       "parallelism": "single GPU" if world == 1 else f"spatial domain decomposition x{world}" + (" (1-GPU rehearsal over gloo)" if rehearsal else ""),
+                       "halo_bytes_per_rank_per_step": None if runner is None else runner.ex.plan.bytes_per_step(),
                        "state_finite": ok},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "lw::k_stream_collide<false>", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "lw::k_stream_collide_xrun<4,false,false>", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_LUP * cells_per_rank,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"},
         }

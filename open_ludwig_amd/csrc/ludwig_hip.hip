@@ -38,7 +38,9 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 0 = all-neighbours kernel, 1 = general kernel, 2 = x-run kernel
-constexpr int XRUN = 4;                     // waves (= x-consecutive blocks) per x-run workgroup
+constexpr int XRUN_MAX = 8;
+static int xrun_len() { static int v = [] { const char *e = getenv("LUDWIG_XRUN"); int n = e ? atoi(e) : 4; return n == 8 ? 8 : 4; }(); return v; }
+#define XRUN (xrun_len())               // waves (= x-consecutive blocks) per x-run workgroup: 4 (default) or 8
 
 }  // namespace
 
@@ -191,7 +193,7 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
         bool any = false;
         for (int32_t it : cls[c]) any = any || it >= 0;
         if (!any) cls[c].clear();
-        while (cls[c].size() % 4) cls[c].push_back(-1);
+        while (cls[c].size() % (c == 2 ? XRUN : 4)) cls[c].push_back(-1);
         if (L->items[part][c]) { (void)hipFree(L->items[part][c]); L->items[part][c] = nullptr; }
         L->n_items[part][c] = (int64_t)cls[c].size();
         if (!cls[c].empty()) {
@@ -227,7 +229,7 @@ int default_items(LudwigLevel *L, int part)
         return a.bx < c.bx;
     });
     auto fast = [&](int b) { return (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0; };
-    struct Group { int32_t by, bx0, bz; int32_t b[XRUN]; };
+    struct Group { int32_t by, bx0, bz; int32_t b[XRUN_MAX]; };
     std::vector<Group> runs;
     std::vector<Blk> singles;
     size_t i = 0;
@@ -336,7 +338,8 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.items = L->items[part][c];
         const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
 #define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, L->stream, p)
-#define LW_LAUNCH_X(P, W) hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, P, W>), dim3((unsigned)(L->n_items[part][c] / XRUN)), dim3(64 * XRUN), 0, L->stream, p)
+#define LW_LAUNCH_X(P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, L->stream, p); \
+            else hipLaunchKernelGGL((k_stream_collide_xrun<4, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, L->stream, p); } while (0)
         if (c == 0) {
             if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
             else      { if (wall) LW_LAUNCH(false, false, true); else LW_LAUNCH(false, false, false); }
@@ -696,7 +699,7 @@ int ludwig_level_info(const LudwigLevel *L, LudwigLevelInfo *info)
     info->n_boundary_cells = L->n_bc;
     info->has_temporal_storage = L->has_temporal;
     info->has_post_collision = L->has_post;
-    info->n_xrun_blocks = (int32_t)(L->n_items[LUDWIG_PART_ALL][2] / 8);
+    info->n_xrun_blocks = (int32_t)(L->n_items[LUDWIG_PART_ALL][2] / 8);   // 8 planes per block
     info->device_bytes = L->device_bytes;
     return LUDWIG_OK;
 }

@@ -102,6 +102,37 @@ def columns(coords, tx: int = 1, ty: int = 0) -> np.ndarray:
     return ((order[:, None] << 3) | z[None, :]).reshape(-1).astype(np.int32)
 
 
+def region_per_xcd(coords, regions=(4, 2), run: int = 4, sweep: str = "yxz", planes_inner: bool = True) -> np.ndarray:
+    """XCD <-> region of (bx,by) block columns: the cross-section is cut into regions[0] x regions[1] = 8 rectangles,
+    XCD i sweeps region i through all bz. A workgroup = one plane of an x-run of `run` blocks; the 8 planes of a run are
+    consecutive workgroups of the same XCD, so x/y face lines AND the z+-1 velocity planes are re-read on the XCD that
+    fetched them; only the region perimeter crosses XCDs."""
+    c = np.asarray(coords).astype(np.int64) - 1
+    nbx, nby = int(c[:, 0].max()) + 1, int(c[:, 1].max()) + 1
+    rx = np.minimum(c[:, 0] * regions[0] // nbx, regions[0] - 1)
+    ry = np.minimum(c[:, 1] * regions[1] // nby, regions[1] - 1)
+    xcd = rx * regions[1] + ry
+    seqs = [[] for _ in range(N_XCD)]
+    for r in range(N_XCD):
+        ids = np.flatnonzero(xcd == r)
+        if ids.size == 0:
+            continue
+        cr = c[ids]
+        x0 = cr[:, 0].min()
+        kx = (cr[:, 0] - x0) // run
+        keys = {"yxz": (cr[:, 1], kx, cr[:, 2]), "zyx": (cr[:, 2], cr[:, 1], kx), "yzx": (cr[:, 1], cr[:, 2], kx), "xyz": (kx, cr[:, 1], cr[:, 2])}[sweep]
+        order = np.lexsort((cr[:, 0],) + keys)         # fastest first: x inside the run, then the sweep keys
+        gkey = np.stack([kx, cr[:, 1], cr[:, 2]], 1)[order]
+        cut = np.flatnonzero(np.r_[True, (gkey[1:] != gkey[:-1]).any(1), True])
+        for i in range(len(cut) - 1):
+            blocks = ids[order[cut[i]:cut[i + 1]]]
+            for z in range(8):
+                items = _pad4((int(b) << 3) | z for b in blocks)
+                for j in range(0, len(items), WAVES):
+                    seqs[r].append(items[j:j + WAVES])
+    return _per_xcd(seqs)
+
+
 BUILDERS = {
     "block_planes": block_planes,
     "pxcd_2x2_xyz": lambda c: plane_per_xcd(c, 2, 2, "xyz"),
@@ -118,6 +149,13 @@ BUILDERS = {
     "pxcdrot_4x1_xyz": lambda c: plane_per_xcd_rot(c, 4, 1, "xyz", "bz"),
     "pxcdrot2_4x1_zxy": lambda c: plane_per_xcd_rot(c, 4, 1, "zxy", "bzy"),
     "pxcd_4x1_yxz": lambda c: plane_per_xcd(c, 4, 1, "yxz"),
+    "reg42_yxz": lambda c: region_per_xcd(c, (4, 2), 4, "yxz"),
+    "reg24_yxz": lambda c: region_per_xcd(c, (2, 4), 4, "yxz"),
+    "reg81_yxz": lambda c: region_per_xcd(c, (8, 1), 4, "yxz"),
+    "reg18_yxz": lambda c: region_per_xcd(c, (1, 8), 4, "yxz"),
+    "reg42_zyx": lambda c: region_per_xcd(c, (4, 2), 4, "zyx"),
+    "reg42_yzx": lambda c: region_per_xcd(c, (4, 2), 4, "yzx"),
+    "reg24_zyx": lambda c: region_per_xcd(c, (2, 4), 4, "zyx"),
     "pxcd_4x1_yzx": lambda c: plane_per_xcd(c, 4, 1, "yzx"),
     "pxcd_4x1_zyx": lambda c: plane_per_xcd(c, 4, 1, "zyx"),
     "pxcdrot_4x1_yxz": lambda c: plane_per_xcd_rot(c, 4, 1, "yxz", "bz"),

@@ -189,12 +189,13 @@ def build_plan(view: LocalView, n_global: int, my_requests: Dict[int, Dict[str, 
 # transport (torch.distributed): pack -> send/recv -> unpack with pluggable pack/unpack
 # ----------------------------------------------------------------------------------------------------------------
 class HaloExchanger:
-    """One exchange = for every peer: pack(send list) -> isend ; irecv -> unpack(recv list).
+    """One exchange = pack(all send lists) -> per peer isend/irecv of slices -> unpack(all recv lists).
 
     pack(name, index_tensor, out_tensor) / unpack(name, index_tensor, in_tensor) are supplied by the caller:
-    HIP gather/scatter kernels on the GPU path, numpy fancy indexing in the CPU (gloo) tests.
-    `device` is where the message buffers live; with backend gloo and GPU buffers the messages are staged through
-    pinned host memory (used to rehearse >1 rank on a single GPU; RCCL refuses two ranks on one device).
+    HIP gather/scatter kernels on the GPU path, numpy fancy indexing in the CPU (gloo) tests. All peers' lists of one
+    field are concatenated, so a step costs 2 pack + 2 unpack launches and one grouped send/recv, however many peers.
+    `device` is where the message buffers live; with `stage_through_host` (backend gloo, GPU buffers) the messages go
+    through pinned host memory - used to rehearse > 1 rank on a single GPU, where RCCL refuses to start.
     """
 
     def __init__(self, plan: HaloPlan, rank: int, device, pack: Callable, unpack: Callable, stage_through_host: bool = False):
@@ -203,57 +204,59 @@ class HaloExchanger:
         self.plan, self.rank = plan, rank
         self.pack, self.unpack = pack, unpack
         self.stage = stage_through_host
-        self.idx_send, self.idx_recv, self.buf_send, self.buf_recv, self.split = {}, {}, {}, {}, {}
-        for p in plan.peers:
-            s, r = plan.send[p], plan.recv[p]
-            self.idx_send[p] = {n: torch.as_tensor(s[n], dtype=torch.int64, device=device) for n in ("f", "vel")}
-            self.idx_recv[p] = {n: torch.as_tensor(r[n], dtype=torch.int64, device=device) for n in ("f", "vel")}
-            self.split[p] = (s["f"].size, r["f"].size)
-            self.buf_send[p] = torch.empty(s["f"].size + s["vel"].size, dtype=torch.float32, device=device)
-            self.buf_recv[p] = torch.empty(r["f"].size + r["vel"].size, dtype=torch.float32, device=device)
+        self.idx_send, self.idx_recv, self.buf_send, self.buf_recv, self.seg_send, self.seg_recv = {}, {}, {}, {}, {}, {}
+        for name in ("f", "vel"):
+            s_lists = [plan.send[p][name] for p in plan.peers]
+            r_lists = [plan.recv[p][name] for p in plan.peers]
+            cat = lambda ls: np.concatenate(ls) if ls else np.zeros(0, np.int64)
+            self.idx_send[name] = torch.as_tensor(cat(s_lists), dtype=torch.int64, device=device)
+            self.idx_recv[name] = torch.as_tensor(cat(r_lists), dtype=torch.int64, device=device)
+            self.buf_send[name] = torch.empty(self.idx_send[name].numel(), dtype=torch.float32, device=device)
+            self.buf_recv[name] = torch.empty(self.idx_recv[name].numel(), dtype=torch.float32, device=device)
+            so = np.concatenate([[0], np.cumsum([len(a) for a in s_lists])]).astype(np.int64)
+            ro = np.concatenate([[0], np.cumsum([len(a) for a in r_lists])]).astype(np.int64)
+            self.seg_send[name] = {p: (int(so[i]), int(so[i + 1])) for i, p in enumerate(plan.peers)}
+            self.seg_recv[name] = {p: (int(ro[i]), int(ro[i + 1])) for i, p in enumerate(plan.peers)}
         if self.stage:
-            self.host_send = {p: torch.empty(self.buf_send[p].numel(), dtype=torch.float32).pin_memory() for p in plan.peers}
-            self.host_recv = {p: torch.empty(self.buf_recv[p].numel(), dtype=torch.float32).pin_memory() for p in plan.peers}
+            self.host_send = {n: torch.empty(self.buf_send[n].numel(), dtype=torch.float32).pin_memory() for n in ("f", "vel")}
+            self.host_recv = {n: torch.empty(self.buf_recv[n].numel(), dtype=torch.float32).pin_memory() for n in ("f", "vel")}
 
     def exchange(self, f_name: str, vel_name: str) -> None:
         """Refresh the ghost elements of fields `f_name` ('f' | 'f_temp') and `vel_name` ('vel' | 'vel_temp')."""
         import torch.distributed as dist
         torch = self.torch
+        fields = {"f": f_name, "vel": vel_name}
+        for n in ("f", "vel"):
+            if self.buf_send[n].numel():
+                self.pack(fields[n], self.idx_send[n], self.buf_send[n])
+        if self.stage:
+            for n in ("f", "vel"):
+                self.host_send[n].copy_(self.buf_send[n], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        snd = self.host_send if self.stage else self.buf_send
+        rcv = self.host_recv if self.stage else self.buf_recv
         ops = []
         for p in self.plan.peers:
-            ns, _ = self.split[p]
-            bs = self.buf_send[p]
-            if ns:
-                self.pack(f_name, self.idx_send[p]["f"], bs[:ns])
-            if bs.numel() - ns:
-                self.pack(vel_name, self.idx_send[p]["vel"], bs[ns:])
-        if self.stage:
-            for p in self.plan.peers:
-                self.host_send[p].copy_(self.buf_send[p], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-        for p in self.plan.peers:
-            snd = self.host_send[p] if self.stage else self.buf_send[p]
-            rcv = self.host_recv[p] if self.stage else self.buf_recv[p]
-            if p == self.rank:
-                rcv.copy_(snd)          # periodic wrap onto oneself (e.g. 1 rank along an axis)
-                continue
-            if snd.numel():
-                ops.append(dist.P2POp(dist.isend, snd, p))
-            if rcv.numel():
-                ops.append(dist.P2POp(dist.irecv, rcv, p))
+            for n in ("f", "vel"):
+                a, b = self.seg_send[n][p]
+                c, d = self.seg_recv[n][p]
+                if p == self.rank:
+                    if d > c:
+                        rcv[n][c:d].copy_(snd[n][a:b])
+                    continue
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, snd[n][a:b], p))
+                if d > c:
+                    ops.append(dist.P2POp(dist.irecv, rcv[n][c:d], p))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if self.stage:
-            for p in self.plan.peers:
-                self.buf_recv[p].copy_(self.host_recv[p], non_blocking=True)
-        for p in self.plan.peers:
-            _, nr = self.split[p]
-            br = self.buf_recv[p]
-            if nr:
-                self.unpack(f_name, self.idx_recv[p]["f"], br[:nr])
-            if br.numel() - nr:
-                self.unpack(vel_name, self.idx_recv[p]["vel"], br[nr:])
+            for n in ("f", "vel"):
+                self.buf_recv[n].copy_(self.host_recv[n], non_blocking=True)
+        for n in ("f", "vel"):
+            if self.buf_recv[n].numel():
+                self.unpack(fields[n], self.idx_recv[n], self.buf_recv[n])
 
 
 def exchange_requests(my_requests: Dict[int, Dict[str, np.ndarray]], world: int, rank: int) -> Dict[int, Dict[str, np.ndarray]]:
