@@ -1,0 +1,94 @@
+"""Case driver: the time loop of src/main.jl:169-232 around the HIP engine (YAML + STL in, Cd/Cl series out).
+
+Loop semantics kept from the reference: steps run in batches of
+`gpu.async_depth`; the inlet speed is the cosine ramp evaluated ONCE per batch at `batch_end`; diagnostics fire when
+`batch_end % diag_freq < batch_length` and look at the state at batch END (stats from level 1's `rho`, forces from the
+finest level's `rho` and `vel` buffer).
+
+The stepping backend is injected (`stepper`), so the same loop drives the HIP library (HipStepper, the product path)
+and, in tests only, the CPU oracle.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import forces as forces_mod
+from .blocks import adapt
+from .preprocess import CaseConfig, DomainParameters, setup_multilevel_domain, solver_params
+from .solver_control import execute_timestep_batch, ramp_velocity
+
+
+@dataclass
+class DiagRow:
+    step: int
+    u_lat: float
+    rho_min: float
+    cd: float
+    cl: float
+    cs: float = 0.0
+    cmy: float = 0.0
+
+
+class HipStepper:
+    """grids on one MI355X behind libludwig_hip.so"""
+
+    def __init__(self, host_grids, device: int = 0):
+        self.host = host_grids
+        self.dev = [adapt(g, device) for g in host_grids]
+        for d in self.dev:
+            d.init_equilibrium()               # src/main.jl:126-135
+
+    def batch(self, t_start: int, n: int, u_curr, params) -> None:
+        execute_timestep_batch(self.dev, t_start, n, u_curr, params)
+
+    def field(self, level: int, name: str) -> np.ndarray:
+        return self.dev[level].download(name)
+
+    def close(self):
+        for d in self.dev:
+            d.close()
+
+
+def flow_stats(rho: np.ndarray, obstacle: np.ndarray) -> float:
+    """rho_min of compute_flow_stats (src/diagnostics.jl:56-94, CUDA branch): minimum over non-obstacle cells"""
+    return float(rho[~obstacle].min())
+
+
+def run_case(cfg: CaseConfig, stepper_factory: Callable = HipStepper, steps: Optional[int] = None, stl_path: Optional[str] = None,
+             log: Optional[Callable[[str], None]] = None, setup=None):
+    """solve_main (src/main.jl:54-249) minus VTK/CSV output. Returns (rows, setup_report, params)."""
+    grids, mesh, params, report = setup if setup is not None else setup_multilevel_domain(cfg, stl_path)
+    sp = solver_params(cfg, params)
+    st = stepper_factory(grids)
+    total_steps = steps if steps is not None else cfg.steps
+    rows: List[DiagRow] = []
+    batch = cfg.async_depth
+    t = 1
+    try:
+        while t <= total_steps:
+            batch_end = min(t + batch - 1, total_steps)
+            actual = batch_end - t + 1
+            u_curr = ramp_velocity(batch_end, cfg.ramp_steps, cfg.u_lattice)
+            st.batch(t, actual, u_curr, sp)
+            if batch_end % cfg.diag_freq < actual or batch_end == total_steps:
+                diag_step = (batch_end // cfg.diag_freq) * cfg.diag_freq
+                if t <= diag_step <= batch_end:
+                    rho1 = st.field(0, "rho")
+                    rho_min = flow_stats(rho1, grids[0].obstacle)
+                    cd = cl = cs = cmy = float("nan")
+                    if cfg.forces_enabled:
+                        fin = len(grids) - 1
+                        rho_f = rho1 if fin == 0 else st.field(fin, "rho")
+                        fr = forces_mod.compute_aerodynamics(mesh, grids[fin], rho_f, st.field(fin, "vel"), params, cfg.symmetric_analysis)
+                        cd, cl, cs, cmy = fr.Cd, fr.Cl, fr.Cs, fr.Cmy
+                    rows.append(DiagRow(diag_step, float(u_curr), rho_min, cd, cl, cs, cmy))
+                    if log:
+                        log(f"{diag_step:8d} | {float(u_curr):.4f} | {rho_min:.4f} | {cd:8.4f} | {cl:8.4f}")
+            t = batch_end + 1
+    finally:
+        if hasattr(st, "close"):
+            st.close()
+    return rows, report, params

@@ -1,8 +1,9 @@
 /*
  * ludwig_oracle.c - scalar FP32 CPU restatement of the OPEN_Ludwig hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see ludwig_oracle.h). "parity unpinned" at unit level:
- * the reference has no golden vectors and cannot be executed in this image.
+ * TEST INFRASTRUCTURE ONLY (see ludwig_oracle.h). Pinned by the reference's run-log series
+ * (tests/test_case_ball1m.py); there are no unit-level reference vectors (the reference
+ * has none and cannot be executed in this image).
  *
  * Every function cites the reference lines it restates (paths under /root/reference).
  * Operation ORDER follows the reference expression by expression; build with

@@ -1,7 +1,7 @@
 """ctypes wrapper of the CPU oracle (oracle/ludwig_oracle.c).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by
-anything under open_ludwig_amd/. "parity unpinned" at unit level - see ludwig_oracle.h.
+anything under open_ludwig_amd/. Pin status: see ludwig_oracle.h (anchored by the reference's run-log series).
 
 It operates IN PLACE on the numpy arrays of host BlockLevel objects (open_ludwig_amd.blocks.BlockLevel), which use
 the reference's memory layout.

@@ -1,0 +1,30 @@
+"""ball1m at the Re 266k settings of the reference's run log: HIP path (and optionally the CPU oracle) vs the log series."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from open_ludwig_amd import preprocess as pp, case
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+osteps = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+G = os.path.join(ROOT, "tests", "golden")
+cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"), {"basic": {"surface_resolution": 25, "flow": {"velocity": 4.0}, "simulation": {"steps": 6000, "output_freq": 1000}}})
+t = time.time(); setup = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl")); print("setup s", round(time.time() - t, 1), setup[3], flush=True)
+log = {int(l.split(",")[0]): [float(v) for v in l.split(",")[1:]] for l in open(os.path.join(G, "sphere_re266k_log.csv")) if l[0].isdigit()}
+t = time.time(); rows, _, params = case.run_case(cfg, case.HipStepper, steps=steps, setup=setup); dt = time.time() - t
+upd = sum(g.n_blocks * 512 * 2 ** i for i, g in enumerate(setup[0])) * steps
+print(f"HIP: {steps} steps in {dt:.1f} s incl. diagnostics -> {upd / dt / 1e6:.0f} MLUPS (true count)")
+print("step   U_lat(log)  rho_min(hip/log)   Cd(hip/log)        Cl(hip/log)")
+for r in rows:
+    if r.step in log:
+        L = log[r.step]
+        print(f"{r.step:5d}  {r.u_lat:.4f}({L[0]:.4f})  {r.rho_min:.4f}/{L[1]:.4f}   {r.cd:.4f}/{L[2]:.4f}   {r.cl:+.4f}/{L[3]:+.4f}")
+if osteps:
+    from _steppers import OracleStepper
+    from oracle import oracle
+    oracle.set_num_threads(16)
+    import copy
+    setup2 = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
+    t = time.time(); orows, _, _ = case.run_case(cfg, OracleStepper, steps=osteps, setup=setup2); print("oracle s", round(time.time() - t, 1))
+    for a in orows:
+        b = [r for r in rows if r.step == a.step][0]
+        print(f"step {a.step}: oracle Cd {a.cd:.8f} Cl {a.cl:.8f} rho_min {a.rho_min:.8f} | hip Cd {b.cd:.8f} Cl {b.cl:.8f} rho_min {b.rho_min:.8f} | rel dCd {abs(a.cd-b.cd)/abs(a.cd):.2e}")
