@@ -158,6 +158,15 @@ int  ludwig_bouzidi_correction(LudwigLevel *level, int64_t t_sub, float q_min_th
 /* copy_to_old!(level, f_in, vel_in) (src/blocks.jl:199-205) for the step t_sub about to run */
 int  ludwig_save_old(LudwigLevel *level, int64_t t_sub);
 
+/*
+ * execute_timestep_batch! (src/solver_control.jl:145-165) in one call: for t = t_start .. t_start+batch_size-1 run
+ * recursive_step!(grids, 1, t, ...) - per level: A/B roles from t_sub parity, copy_to_old! when the level has children
+ * and temporal interpolation is on, perform_timestep_v2!, then the child level twice (2 t_sub with temporal weight 0.0,
+ * 2 t_sub + 1 with 0.5) - and synchronize at the end like the reference. levels[0] is level 1; all on one device.
+ */
+int  ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, int64_t t_start, int32_t batch_size,
+                                   float u_curr, const LudwigStepFlags *flags);
+
 /* KernelAbstractions.synchronize(backend) (src/solver_control.jl:164) */
 int  ludwig_sync(const LudwigLevel *level);
 

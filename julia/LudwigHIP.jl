@@ -114,12 +114,13 @@ function recursive_step!(grids::Vector{DeviceLevel}, lvl::Int, t_sub::Int, paren
     end
 end
 
-"""execute_timestep_batch! (src/solver_control.jl:145-165)"""
+"""execute_timestep_batch! (src/solver_control.jl:145-165): the whole batch in one ccall (the library runs the same
+recursion); `recursive_step!` above is the call-by-call equivalent."""
 function execute_timestep_batch!(grids::Vector{DeviceLevel}, t_start::Int, batch_size::Int, u_curr::Float32, flags::StepFlags)
-    for t_offset in 0:(batch_size - 1)
-        recursive_step!(grids, 1, t_start + t_offset, nothing, 0.5f0, 0.0f0, u_curr, flags)
-    end
-    synchronize(grids[1])
+    handles = Ptr{Cvoid}[g.handle for g in grids]
+    GC.@preserve handles check(ccall((:ludwig_execute_timestep_batch, LIB), Cint,
+                                     (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Cfloat, Ref{StepFlags}),
+                                     handles, Int32(length(grids)), Int64(t_start), Int32(batch_size), u_curr, flags))
 end
 
 end # module

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "ludwig_level_create", "ludwig_level_destroy", "ludwig_level_set_stream", "ludwig_level_set_order",
     "ludwig_level_upload", "ludwig_level_download", "ludwig_level_field_ptr",
     "ludwig_init_equilibrium", "ludwig_step", "ludwig_stream_collide", "ludwig_bouzidi_correction",
-    "ludwig_save_old", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
+    "ludwig_save_old", "ludwig_execute_timestep_batch", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
 ]
 
 
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
         "ludwig_stream_collide": (C.c_int, [vp, vp, i64, f32, f32, f32, C.POINTER(StepFlags), i32]),
         "ludwig_bouzidi_correction": (C.c_int, [vp, i64, f32]),
         "ludwig_save_old": (C.c_int, [vp, i64]),
+        "ludwig_execute_timestep_batch": (C.c_int, [C.POINTER(vp), i32, i64, i32, f32, C.POINTER(StepFlags)]),
         "ludwig_sync": (C.c_int, [vp]),
         "ludwig_halo_pack": (C.c_int, [vp, i32, vp, i64, vp, vp]),
         "ludwig_halo_unpack": (C.c_int, [vp, i32, vp, i64, vp, vp]),

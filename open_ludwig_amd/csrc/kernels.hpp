@@ -225,7 +225,11 @@ __device__ __noinline__ void wall_model_force(float dist_wall, float tau_molecul
 // cell inside one population is (block * 512 + cell) * 4 < 2^32 (checked at level creation).
 __device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off)
 {
+#ifdef LW_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off));
+#else
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+#endif
 }
 __device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v)
 {

@@ -657,6 +657,40 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
     return LUDWIG_OK;
 }
 
+static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-based*/, int64_t t_sub, const LudwigLevel *parent,
+                          float parent_tau, float temporal_weight, float u_vel, const LudwigStepFlags *fl)
+{
+    // recursive_step! / recursive_step_temporal!, reference src/solver_control.jl:21-143
+    if (lvl > n_levels) return LUDWIG_OK;
+    LudwigLevel *L = levels[lvl - 1];
+    const bool has_children = lvl < n_levels;
+    int rc;
+    if (has_children && fl->use_temporal_interp && L->has_temporal)
+        if ((rc = ludwig_save_old(L, t_sub))) return rc;
+    if ((rc = ludwig_step(L, parent, t_sub, u_vel, parent_tau, temporal_weight, fl))) return rc;
+    if (has_children) {
+        if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub, L, L->tau, 0.0f, u_vel, fl))) return rc;
+        if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub + 1, L, L->tau, 0.5f, u_vel, fl))) return rc;
+    }
+    return LUDWIG_OK;
+}
+
+int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, int64_t t_start, int32_t batch_size, float u_curr,
+                                  const LudwigStepFlags *flags)
+{
+    if (!levels || !flags || n_levels < 1 || batch_size < 0) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n_levels; ++i) {
+        if (!levels[i]) return fail(LUDWIG_ERR_INVALID, "null level %d", i + 1);
+        if (levels[i]->device != levels[0]->device || levels[i]->stream != levels[0]->stream)
+            return fail(LUDWIG_ERR_INVALID, "all levels must share one device and one stream");
+    }
+    for (int32_t o = 0; o < batch_size; ++o) {
+        const int rc = recursive_step(levels, n_levels, 1, t_start + o, nullptr, 0.5f, 0.0f, u_curr, flags);
+        if (rc) return rc;
+    }
+    return ludwig_sync(levels[0]);
+}
+
 int ludwig_sync(const LudwigLevel *L)
 {
     if (!L) return fail(LUDWIG_ERR_INVALID, "null level");

@@ -37,8 +37,20 @@ def recursive_step(grids: Sequence[DeviceLevel], current_lvl: int, t_sub: int, p
 
 
 def execute_timestep_batch(grids: Sequence[DeviceLevel], t_start: int, batch_size: int, u_curr,
-                           params: SolverParams) -> None:
-    """execute_timestep_batch! (src/solver_control.jl:145-165); t_start is 1-based like the reference's loop."""
+                           params: SolverParams, native: bool = True) -> None:
+    """execute_timestep_batch! (src/solver_control.jl:145-165); t_start is 1-based like the reference's loop.
+
+    native=True (default): the whole batch is one C call (ludwig_execute_timestep_batch runs the same recursion inside
+    the library, so a multi-level coarse step is not paced by Python). native=False: the recursion of this module, call
+    by call - the two are tested to give identical results."""
+    if native:
+        import ctypes as C
+        from . import _lib
+        arr = (C.c_void_p * len(grids))(*[g.handle for g in grids])
+        fl = params.to_c()
+        _lib.check(_lib.load().ludwig_execute_timestep_batch(arr, len(grids), int(t_start), int(batch_size),
+                                                             float(np.float32(u_curr)), C.byref(fl)))
+        return
     for t_offset in range(batch_size):
         t = t_start + t_offset
         recursive_step(grids, 1, t, None, np.float32(0.5), u_curr, params)

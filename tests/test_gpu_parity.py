@@ -122,6 +122,22 @@ def test_tunnel_symmetric_no_blend(gpu):
     compare(grids, dev, 3)
 
 
+def test_native_batch_driver_equals_python_recursion(gpu):
+    """ludwig_execute_timestep_batch (row H inside the library) vs the call-by-call mirror of solver_control.jl."""
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3)
+    a = [adapt(g, 0) for g in grids]
+    b = [adapt(g, 0) for g in grids]
+    execute_timestep_batch(a, 1, 3, np.float32(0.05), params, native=True)
+    execute_timestep_batch(b, 1, 3, np.float32(0.05), params, native=False)
+    for i in range(3):
+        for name in ("f", "f_temp", "vel", "vel_temp", "rho", "f_old", "rho_old", "vel_old"):
+            if i == 2 and name.endswith("_old"):
+                continue
+            assert np.array_equal(a[i].download(name), b[i].download(name)), (i, name)
+    for d in a + b:
+        d.close()
+
+
 def test_tunnel_batches_match_single_batch(gpu):
     """execute_timestep_batch! called in batches of 2 (async_depth) must give what one long batch gives."""
     grids, params = cases.tunnel_with_sphere((5, 3, 3), levels=2)
