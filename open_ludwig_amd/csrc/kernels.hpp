@@ -44,6 +44,10 @@ struct SCParams {
     float tau, tau_parent, c_wale, nu_bg, u_inlet, inlet_turbulence, temporal_weight;
     int32_t is_level_1, is_symmetric, nx_g, ny_g, nz_g;
     int32_t wall_model, seed, use_temporal, sponge_blend;
+    // coarse -> fine interface pass: values of interpolate_with_rescaling for every (cell, population) link of this
+    // level that needs one, precomputed densely by k_interface_links: f_iface[(k * n_iface_blocks + gbi) * 512 + cell]
+    float *f_iface;
+    int32_t n_iface_blocks;
 };
 
 template <int K, int N, class F>
@@ -544,7 +548,8 @@ __global__ __launch_bounds__(256) LW_WAVES_ATTR void k_stream_collide(const SCPa
                 } else if (is_z_min || is_z_max) {
                     val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
                 } else if (p.is_level_1 == 0) {
-                    val = interpolate_with_rescaling(p, src_gx, src_gy, src_gz, k, WEIGHT(k), (float)cx, (float)cy, (float)cz);
+                    // value computed by k_interface_links for exactly this (cell, k) link (same function, same inputs)
+                    val = p.f_iface[((size_t)k * p.n_iface_blocks + meta[NBR_GBI]) * CELLS + (own_bytes >> 2) - (size_t)b * CELLS];
                 } else {
                     val = WEIGHT(k);
                 }
@@ -695,6 +700,33 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     }
     finish_cell<POST, WALL>(p, flags, own_bytes, fs, uE[0], uE[1], uE[2], uW[0], uW[1], uW[2], uN[0], uN[1], uN[2], uS[0], uS[1], uS[2],
                             uT[0], uT[1], uT[2], uB[0], uB[1], uB[2]);
+}
+
+// ---- coarse -> fine interface pass (reference src/physics_kernels.jl:122-137 + src/physics_interpolation.jl) ----
+// The reference evaluates interpolate_with_rescaling inline, for the few lanes of a refinement-edge block whose source
+// block is missing. Done that way on a 64-wide wavefront it is 27 divergent call sites at ~12 % lane utilisation and
+// took 86 % of the GPU time of a 3-level case (profiles/r01_ball1m_kernel_stats_before_interface_pass.csv). The links
+// that need it are a static property of the level (topology + global box), so the host lists them once and this kernel
+// evaluates one link per lane; the stream-collide kernel then loads the value. Same function, same inputs: bit-identical.
+__device__ __forceinline__ float weight_rt(int k)
+{
+    const int cx = k % 3 - 1, cy = (k / 3) % 3 - 1, cz = k / 9 - 1;
+    const int d2 = cx * cx + cy * cy + cz * cz;
+    return d2 == 0 ? WEIGHT(13) : d2 == 1 ? WEIGHT(12) : d2 == 2 ? WEIGHT(9) : WEIGHT(0);
+}
+
+__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const int2 *__restrict__ links, int n_links)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_links) return;
+    const int2 l = links[i];
+    const int b = l.x >> 9, cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5;
+    const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+    const int cx = k % 3 - 1, cy = (k / 3) % 3 - 1, cz = k / 9 - 1;
+    const int32_t *meta = p.meta + (size_t)b * NBR_STRIDE;
+    const int gx = (meta[NBR_BX] - 1) * BS + x + 1, gy = (meta[NBR_BY] - 1) * BS + y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
+    const float v = interpolate_with_rescaling(p, gx - cx, gy - cy, gz - cz, k, weight_rt(k), (float)cx, (float)cy, (float)cz);
+    p.f_iface[((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell] = v;
 }
 
 // ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----

@@ -26,10 +26,11 @@ __host__ __device__ constexpr int DIR(int ox, int oy, int oz) { return (ox + 1) 
 constexpr float KAPPA = 0.41f;              // reference src/physics_v2.jl:15
 constexpr float CS2_PHYSICS = 1.0f / 3.0f;  // reference src/physics_v2.jl:16
 
-// per-block metadata row: [0..26] neighbour block (0-based, -1 absent), [27] flags, [28..30] bx,by,bz (1-based)
+// per-block metadata row: [0..26] neighbour block (0-based, -1 absent), [27] flags, [28..30] bx,by,bz (1-based), [31] gbi
 constexpr int NBR_STRIDE = 32;
 constexpr int NBR_FLAGS = 27;
 constexpr int NBR_BX = 28, NBR_BY = 29, NBR_BZ = 30;
+constexpr int NBR_GBI = 31;              // compact index of the block among the level's interface (general) blocks, or -1
 
 constexpr int FLAG_ALL_NEIGHBOURS = 1;   // all 26 neighbour blocks present -> no domain-edge / interface code
 constexpr int FLAG_HAS_OBSTACLE = 2;

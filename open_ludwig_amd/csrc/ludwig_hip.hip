@@ -68,6 +68,12 @@ struct LudwigLevel {
     int64_t n_items[N_PARTS][N_CLASSES] = {};
     int n_fast_blocks = 0;
     int64_t device_bytes = 0;
+    // coarse -> fine interface pass (levels >= 2): links per part, built lazily for the global box of the first step
+    int n_iface_blocks = 0;
+    float *f_iface = nullptr;
+    int2 *links[N_PARTS] = {};
+    int n_links[N_PARTS] = {};
+    int iface_dims[3] = {-1, -1, -1};
 };
 
 namespace {
@@ -277,6 +283,50 @@ int default_items(LudwigLevel *L, int part)
     return set_items(L, part, seq.data(), (int64_t)seq.size());
 }
 
+// Links (cell, population) of the interface blocks whose source block is missing and for which the reference's
+// domain-edge chain (src/physics_kernels.jl:88-140) selects the parent interpolation: source inside the global box.
+int build_interface_links(LudwigLevel *L, int nx_g, int ny_g, int nz_g)
+{
+    if (L->iface_dims[0] == nx_g && L->iface_dims[1] == ny_g && L->iface_dims[2] == nz_g) return LUDWIG_OK;
+    LW_HIP(hipStreamSynchronize(L->stream));
+    std::vector<int2> lists[N_PARTS];
+    for (int b = 0; b < L->n_owned; ++b) {
+        const int32_t *row = &L->h_meta[(size_t)b * NBR_STRIDE];
+        const int gbi = row[NBR_GBI];
+        if (gbi < 0) continue;
+        const bool bnd = !L->h_comm_boundary.empty() && L->h_comm_boundary[b] != 0;
+        for (int cell = 0; cell < CELLS; ++cell) {
+            const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+            if (x > 0 && x < 7 && y > 0 && y < 7 && z > 0 && z < 7) continue;
+            const int gx = (row[NBR_BX] - 1) * BS + x + 1, gy = (row[NBR_BY] - 1) * BS + y + 1, gz = (row[NBR_BZ] - 1) * BS + z + 1;
+            for (int k = 0; k < Q; ++k) {
+                const int sx = x - CX(k), sy = y - CY(k), sz = z - CZ(k);
+                const int ox = sx < 0 ? -1 : (sx > 7 ? 1 : 0), oy = sy < 0 ? -1 : (sy > 7 ? 1 : 0), oz = sz < 0 ? -1 : (sz > 7 ? 1 : 0);
+                if ((ox | oy | oz) == 0 || row[DIR(ox, oy, oz)] >= 0) continue;
+                const int src_gx = gx - CX(k), src_gy = gy - CY(k), src_gz = gz - CZ(k);
+                if (src_gx < 1 || src_gx > nx_g || src_gy < 1 || src_gy > ny_g || src_gz < 1 || src_gz > nz_g) continue;   // inlet / outlet / mirror win
+                const int2 e = make_int2((b << 9) | cell, (gbi << 5) | k);
+                lists[LUDWIG_PART_ALL].push_back(e);
+                lists[bnd ? LUDWIG_PART_BOUNDARY : LUDWIG_PART_INTERIOR].push_back(e);
+            }
+        }
+    }
+    for (int a2 = 0; a2 < N_PARTS; ++a2) {
+        if (L->links[a2]) { (void)hipFree(L->links[a2]); L->links[a2] = nullptr; }
+        L->n_links[a2] = (int)lists[a2].size();
+        if (!lists[a2].empty()) {
+            LW_HIP(hipMalloc((void **)&L->links[a2], lists[a2].size() * sizeof(int2)));
+            LW_HIP(hipMemcpy(L->links[a2], lists[a2].data(), lists[a2].size() * sizeof(int2), hipMemcpyHostToDevice));
+        }
+    }
+    if (!L->f_iface && L->n_iface_blocks > 0) {
+        LW_HIP(hipMalloc((void **)&L->f_iface, (size_t)L->n_iface_blocks * CELLS * Q * sizeof(float)));
+        L->device_bytes += (int64_t)L->n_iface_blocks * CELLS * Q * 4;
+    }
+    L->iface_dims[0] = nx_g; L->iface_dims[1] = ny_g; L->iface_dims[2] = nz_g;
+    return LUDWIG_OK;
+}
+
 int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float u_curr, float parent_tau,
                           float temporal_weight, const LudwigStepFlags *fl, int part)
 {
@@ -333,6 +383,17 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     p.sponge_blend = fl->sponge_blend_distributions ? 1 : 0;
 
     const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
+    if (parent && L->n_items[part][1] > 0) {
+        // coarse -> fine interface pass for the general blocks of this part (reference src/physics_kernels.jl:122-137)
+        const int r = build_interface_links(L, p.nx_g, p.ny_g, p.nz_g);
+        if (r) return r;
+        p.f_iface = L->f_iface;
+        p.n_iface_blocks = L->n_iface_blocks;
+        if (L->n_links[part] > 0) {
+            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_links[part] + 255) / 256)), dim3(256), 0, L->stream, p, L->links[part], L->n_links[part]);
+            LW_HIP(hipGetLastError());
+        }
+    }
     for (int c = 0; c < N_CLASSES; ++c) {
         if (L->n_items[part][c] == 0) continue;
         p.items = L->items[part][c];
@@ -404,9 +465,12 @@ void ludwig_level_destroy(LudwigLevel *L)
                     L->sponge, L->wall_dist, L->meta, L->block_pointer, L->q_map, L->cell_block, L->cell_x, L->cell_y, L->cell_z};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (int a = 0; a < N_PARTS; ++a)
+    for (int a = 0; a < N_PARTS; ++a) {
         for (int c = 0; c < N_CLASSES; ++c)
             if (L->items[a][c]) (void)hipFree(L->items[a][c]);
+        if (L->links[a]) (void)hipFree(L->links[a]);
+    }
+    if (L->f_iface) (void)hipFree(L->f_iface);
     delete L;
 }
 
@@ -492,6 +556,9 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     scan_flags(L, LUDWIG_WALL_DIST, h->wall_dist);
     for (int b = 0; b < n_owned; ++b)
         if (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) ++L->n_fast_blocks;
+    for (size_t b = 0; b < nb; ++b) L->h_meta[b * NBR_STRIDE + NBR_GBI] = -1;
+    for (int b = 0; b < n_owned; ++b)
+        if (!(L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS)) L->h_meta[(size_t)b * NBR_STRIDE + NBR_GBI] = L->n_iface_blocks++;
 
     auto init = [&]() -> int {
         // constructor defaults, reference src/blocks.jl:118-150
