@@ -715,18 +715,84 @@ __device__ __forceinline__ float weight_rt(int k)
     return d2 == 0 ? WEIGHT(13) : d2 == 1 ? WEIGHT(12) : d2 == 2 ? WEIGHT(9) : WEIGHT(0);
 }
 
-__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const int2 *__restrict__ links, int n_links)
+// corner data of one parent cell: macroscopic part (shared by all populations of a source cell)
+struct CornerRef {
+    int64_t c;       // cell offset in the parent arrays, -1 = invalid corner
+};
+
+__global__ __launch_bounds__(128) void k_interface_links(const SCParams p, const int4 *__restrict__ sources, int n_sources,
+                                                          const int2 *__restrict__ links)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_links) return;
-    const int2 l = links[i];
-    const int b = l.x >> 9, cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5;
-    const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
-    const int cx = k % 3 - 1, cy = (k / 3) % 3 - 1, cz = k / 9 - 1;
-    const int32_t *meta = p.meta + (size_t)b * NBR_STRIDE;
-    const int gx = (meta[NBR_BX] - 1) * BS + x + 1, gy = (meta[NBR_BY] - 1) * BS + y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
-    const float v = interpolate_with_rescaling(p, gx - cx, gy - cy, gz - cz, k, weight_rt(k), (float)cx, (float)cy, (float)cz);
-    p.f_iface[((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell] = v;
+    // one thread per SOURCE cell (a fine-grid cell just outside this level's blocks): the trilinear rho / u of
+    // reference src/physics_interpolation.jl:110-124 are the same for every population pulled from it, so they are
+    // computed once; then one f interpolation per link. Expression by expression identical to interpolate_with_rescaling.
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= n_sources) return;
+    const int4 s = sources[i];                       // fine_gx, fine_gy, fine_gz, first link
+    const int last = sources[i + 1].w;               // sentinel entry closes the last segment
+    const float px_cont = ((float)s.x - 0.5f) * 0.5f, py_cont = ((float)s.y - 0.5f) * 0.5f, pz_cont = ((float)s.z - 0.5f) * 0.5f;
+    int px0 = (int)floorf(px_cont), py0 = (int)floorf(py_cont), pz0 = (int)floorf(pz_cont);
+    const int px1 = px0 + 1, py1 = py0 + 1, pz1 = pz0 + 1;
+    const float wx = px_cont - (float)px0, wy = py_cont - (float)py0, wz = pz_cont - (float)pz0;
+    px0 = max(1, px0); py0 = max(1, py0); pz0 = max(1, pz0);
+    const bool blend = p.use_temporal == 1 && p.temporal_weight < 0.99f;
+    const float tw = p.temporal_weight;
+    int64_t cc[8];
+    float rho_c[8], ux_c[8], uy_c[8], uz_c[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {                    // corner order 000,100,010,110,001,101,011,111
+        const int pgx = (n & 1) ? px1 : px0, pgy = (n & 2) ? py1 : py0, pgz = (n & 4) ? pz1 : pz0;
+        const int pbx = (pgx - 1) / BS + 1, pby = (pgy - 1) / BS + 1, pbz = (pgz - 1) / BS + 1;
+        cc[n] = -1;
+        rho_c[n] = 1.0f; ux_c[n] = 0.0f; uy_c[n] = 0.0f; uz_c[n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
+        if (pbx >= 1 && pbx <= p.pdim_x && pby >= 1 && pby <= p.pdim_y && pbz >= 1 && pbz <= p.pdim_z) {
+            const int32_t pb = p.pptr[(int64_t)(pbx - 1) + (int64_t)p.pdim_x * ((int64_t)(pby - 1) + (int64_t)p.pdim_y * (pbz - 1))];
+            if (pb > 0) {
+                const int64_t c = (int64_t)((pgx - 1) % BS) + 8 * ((pgy - 1) % BS) + 64 * ((pgz - 1) % BS) + 512 * (int64_t)(pb - 1);
+                cc[n] = c;
+                const float rn = p.prho_new[c], un = p.pvel_new[c], vn = p.pvel_new[c + p.psk], wn = p.pvel_new[c + 2 * p.psk];
+                if (blend) {
+                    rho_c[n] = p.prho_old[c] * (1.0f - tw) + rn * tw;
+                    ux_c[n] = p.pvel_old[c] * (1.0f - tw) + un * tw;
+                    uy_c[n] = p.pvel_old[c + p.psk] * (1.0f - tw) + vn * tw;
+                    uz_c[n] = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + wn * tw;
+                } else {
+                    rho_c[n] = rn; ux_c[n] = un; uy_c[n] = vn; uz_c[n] = wn;
+                }
+            }
+        }
+    }
+    // invalid corners take corner 000's tuple (which may itself be the default), reference :100-107
+#pragma unroll
+    for (int n = 1; n < 8; ++n)
+        if (cc[n] < 0) { rho_c[n] = rho_c[0]; ux_c[n] = ux_c[0]; uy_c[n] = uy_c[0]; uz_c[n] = uz_c[0]; }
+    const float rho_int = trilin(rho_c[0], rho_c[1], rho_c[2], rho_c[3], rho_c[4], rho_c[5], rho_c[6], rho_c[7], wx, wy, wz);
+    const float ux_int = trilin(ux_c[0], ux_c[1], ux_c[2], ux_c[3], ux_c[4], ux_c[5], ux_c[6], ux_c[7], wx, wy, wz);
+    const float uy_int = trilin(uy_c[0], uy_c[1], uy_c[2], uy_c[3], uy_c[4], uy_c[5], uy_c[6], uy_c[7], wx, wy, wz);
+    const float uz_int = trilin(uz_c[0], uz_c[1], uz_c[2], uz_c[3], uz_c[4], uz_c[5], uz_c[6], uz_c[7], wx, wy, wz);
+    const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
+    const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
+    for (int j = s.w; j < last; ++j) {
+        const int2 l = links[j];
+        const int cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5;
+        const float w_k = weight_rt(k);
+        float fc[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            fc[n] = w_k;
+            if (cc[n] >= 0) {
+                const float fn = p.pf_new[cc[n] + p.psk * k];
+                fc[n] = blend ? p.pf_old[cc[n] + p.psk * k] * (1.0f - tw) + fn * tw : fn;
+            }
+        }
+#pragma unroll
+        for (int n = 1; n < 8; ++n)
+            if (cc[n] < 0) fc[n] = fc[0];
+        const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], wx, wy, wz);
+        const float feq_int = calculate_equilibrium(rho_int, ux_int, uy_int, uz_int, w_k, (float)(k % 3 - 1), (float)((k / 3) % 3 - 1), (float)(k / 9 - 1));
+        const float f_neq = f_int - feq_int;
+        p.f_iface[((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell] = feq_int + f_neq * scale;
+    }
 }
 
 // ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----
@@ -742,41 +808,41 @@ struct BouzidiParams {
     float q_min;
 };
 
-__global__ __launch_bounds__(64) void k_bouzidi(const BouzidiParams p)
+// one thread per (listed cell, link k): the 27 links of a cell are independent (each writes its own f_out[cell][opp k]
+// and reads only f_post_collision), so spreading them over lanes changes nothing but the latency that is exposed
+__global__ __launch_bounds__(256) void k_bouzidi(const BouzidiParams p)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= p.n_cells) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n_cells * Q) return;
+    const int c = i / Q, k = i - c * Q;
+    const int opp_k = 26 - k;
     const int b = p.cell_block[c];
     const int x = p.cell_x[c], y = p.cell_y[c], z = p.cell_z[c];
     const int64_t own = (int64_t)b * CELLS + x + 8 * y + 64 * z;
-    static_for<0, Q>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        constexpr int opp_k = OPP(k);
-        const float q = (float)p.q_map[own + p.sk * k];
-        if (q > p.q_min && q <= 1.0f) {
-            const float f_k = p.f_post[own + p.sk * k];
-            if (q < 0.5f) {
-                const int nx = x + CX(opp_k), ny = y + CY(opp_k), nz = z + CZ(opp_k);
-                float f_ff = f_k;
-                if (nx >= 0 && nx < BS && ny >= 0 && ny < BS && nz >= 0 && nz < BS) {
-                    f_ff = p.f_post[(int64_t)b * CELLS + nx + 8 * ny + 64 * nz + p.sk * k];
-                } else {
-                    const int ox = nx < 0 ? -1 : (nx >= BS ? 1 : 0);
-                    const int oy = ny < 0 ? -1 : (ny >= BS ? 1 : 0);
-                    const int oz = nz < 0 ? -1 : (nz >= BS ? 1 : 0);
-                    const int nbb = p.meta[(int64_t)b * NBR_STRIDE + DIR(ox, oy, oz)];
-                    if (nbb >= 0) f_ff = p.f_post[(int64_t)nbb * CELLS + (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7) + p.sk * k];
-                }
-                const float coeff1 = 2.0f * q;
-                p.f_out[own + p.sk * opp_k] = coeff1 * f_k + (1.0f - coeff1) * f_ff;
+    const float q = (float)p.q_map[own + p.sk * k];
+    if (q > p.q_min && q <= 1.0f) {
+        const float f_k = p.f_post[own + p.sk * k];
+        if (q < 0.5f) {
+            const int nx = x + (opp_k % 3 - 1), ny = y + ((opp_k / 3) % 3 - 1), nz = z + (opp_k / 9 - 1);
+            float f_ff = f_k;
+            if (nx >= 0 && nx < BS && ny >= 0 && ny < BS && nz >= 0 && nz < BS) {
+                f_ff = p.f_post[(int64_t)b * CELLS + nx + 8 * ny + 64 * nz + p.sk * k];
             } else {
-                const float f_opp_post = p.f_post[own + p.sk * opp_k];
-                const float inv_2q = 1.0f / (2.0f * q);
-                const float coeff2 = (2.0f * q - 1.0f) * inv_2q;
-                p.f_out[own + p.sk * opp_k] = inv_2q * f_k + coeff2 * f_opp_post;
+                const int ox = nx < 0 ? -1 : (nx >= BS ? 1 : 0);
+                const int oy = ny < 0 ? -1 : (ny >= BS ? 1 : 0);
+                const int oz = nz < 0 ? -1 : (nz >= BS ? 1 : 0);
+                const int nbb = p.meta[(int64_t)b * NBR_STRIDE + DIR(ox, oy, oz)];
+                if (nbb >= 0) f_ff = p.f_post[(int64_t)nbb * CELLS + (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7) + p.sk * k];
             }
+            const float coeff1 = 2.0f * q;
+            p.f_out[own + p.sk * opp_k] = coeff1 * f_k + (1.0f - coeff1) * f_ff;
+        } else {
+            const float f_opp_post = p.f_post[own + p.sk * opp_k];
+            const float inv_2q = 1.0f / (2.0f * q);
+            const float coeff2 = (2.0f * q - 1.0f) * inv_2q;
+            p.f_out[own + p.sk * opp_k] = inv_2q * f_k + coeff2 * f_opp_post;
         }
-    });
+    }
 }
 
 // ---- init_eq!, reference src/main.jl:109-124 ----

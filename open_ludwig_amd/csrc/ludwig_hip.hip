@@ -72,7 +72,9 @@ struct LudwigLevel {
     int n_iface_blocks = 0;
     float *f_iface = nullptr;
     int2 *links[N_PARTS] = {};
+    int4 *sources[N_PARTS] = {};        // per source cell: fine gx, gy, gz, first link; one sentinel at the end
     int n_links[N_PARTS] = {};
+    int n_sources[N_PARTS] = {};
     int iface_dims[3] = {-1, -1, -1};
 };
 
@@ -289,7 +291,8 @@ int build_interface_links(LudwigLevel *L, int nx_g, int ny_g, int nz_g)
 {
     if (L->iface_dims[0] == nx_g && L->iface_dims[1] == ny_g && L->iface_dims[2] == nz_g) return LUDWIG_OK;
     LW_HIP(hipStreamSynchronize(L->stream));
-    std::vector<int2> lists[N_PARTS];
+    struct Link { int64_t key; int sx, sy, sz; int2 e; };
+    std::vector<Link> raw[N_PARTS];
     for (int b = 0; b < L->n_owned; ++b) {
         const int32_t *row = &L->h_meta[(size_t)b * NBR_STRIDE];
         const int gbi = row[NBR_GBI];
@@ -305,18 +308,31 @@ int build_interface_links(LudwigLevel *L, int nx_g, int ny_g, int nz_g)
                 if ((ox | oy | oz) == 0 || row[DIR(ox, oy, oz)] >= 0) continue;
                 const int src_gx = gx - CX(k), src_gy = gy - CY(k), src_gz = gz - CZ(k);
                 if (src_gx < 1 || src_gx > nx_g || src_gy < 1 || src_gy > ny_g || src_gz < 1 || src_gz > nz_g) continue;   // inlet / outlet / mirror win
-                const int2 e = make_int2((b << 9) | cell, (gbi << 5) | k);
-                lists[LUDWIG_PART_ALL].push_back(e);
-                lists[bnd ? LUDWIG_PART_BOUNDARY : LUDWIG_PART_INTERIOR].push_back(e);
+                const Link l{((int64_t)src_gz * (ny_g + 2) + src_gy) * (nx_g + 2) + src_gx, src_gx, src_gy, src_gz, make_int2((b << 9) | cell, (gbi << 5) | k)};
+                raw[LUDWIG_PART_ALL].push_back(l);
+                raw[bnd ? LUDWIG_PART_BOUNDARY : LUDWIG_PART_INTERIOR].push_back(l);
             }
         }
     }
     for (int a2 = 0; a2 < N_PARTS; ++a2) {
+        std::stable_sort(raw[a2].begin(), raw[a2].end(), [](const Link &u, const Link &v) { return u.key < v.key; });
+        std::vector<int2> links;
+        std::vector<int4> src;
+        for (size_t i = 0; i < raw[a2].size(); ++i) {
+            if (i == 0 || raw[a2][i].key != raw[a2][i - 1].key) src.push_back(make_int4(raw[a2][i].sx, raw[a2][i].sy, raw[a2][i].sz, (int)i));
+            links.push_back(raw[a2][i].e);
+        }
+        const int nsrc = (int)src.size();
+        src.push_back(make_int4(0, 0, 0, (int)links.size()));     // sentinel
         if (L->links[a2]) { (void)hipFree(L->links[a2]); L->links[a2] = nullptr; }
-        L->n_links[a2] = (int)lists[a2].size();
-        if (!lists[a2].empty()) {
-            LW_HIP(hipMalloc((void **)&L->links[a2], lists[a2].size() * sizeof(int2)));
-            LW_HIP(hipMemcpy(L->links[a2], lists[a2].data(), lists[a2].size() * sizeof(int2), hipMemcpyHostToDevice));
+        if (L->sources[a2]) { (void)hipFree(L->sources[a2]); L->sources[a2] = nullptr; }
+        L->n_links[a2] = (int)links.size();
+        L->n_sources[a2] = nsrc;
+        if (!links.empty()) {
+            LW_HIP(hipMalloc((void **)&L->links[a2], links.size() * sizeof(int2)));
+            LW_HIP(hipMemcpy(L->links[a2], links.data(), links.size() * sizeof(int2), hipMemcpyHostToDevice));
+            LW_HIP(hipMalloc((void **)&L->sources[a2], src.size() * sizeof(int4)));
+            LW_HIP(hipMemcpy(L->sources[a2], src.data(), src.size() * sizeof(int4), hipMemcpyHostToDevice));
         }
     }
     if (!L->f_iface && L->n_iface_blocks > 0) {
@@ -390,7 +406,8 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.f_iface = L->f_iface;
         p.n_iface_blocks = L->n_iface_blocks;
         if (L->n_links[part] > 0) {
-            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_links[part] + 255) / 256)), dim3(256), 0, L->stream, p, L->links[part], L->n_links[part]);
+            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_sources[part] + 127) / 128)), dim3(128), 0, L->stream, p, L->sources[part],
+                               L->n_sources[part], L->links[part]);
             LW_HIP(hipGetLastError());
         }
     }
@@ -434,7 +451,7 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
     p.sk = L->sk;
     p.n_cells = L->n_bc;
     p.q_min = q_min;
-    hipLaunchKernelGGL(k_bouzidi, dim3((unsigned)((L->n_bc + 63) / 64)), dim3(64), 0, L->stream, p);
+    hipLaunchKernelGGL(k_bouzidi, dim3((unsigned)(((int64_t)L->n_bc * Q + 255) / 256)), dim3(256), 0, L->stream, p);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -469,6 +486,7 @@ void ludwig_level_destroy(LudwigLevel *L)
         for (int c = 0; c < N_CLASSES; ++c)
             if (L->items[a][c]) (void)hipFree(L->items[a][c]);
         if (L->links[a]) (void)hipFree(L->links[a]);
+        if (L->sources[a]) (void)hipFree(L->sources[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
     delete L;
