@@ -82,7 +82,8 @@ typedef struct LudwigLevelHost {
     const float   *sponge;         /* optional */
     const float   *wall_dist;      /* optional */
     int32_t enable_temporal_interpolation;        /* allocate f_old/rho_old/vel_old (src/blocks.jl:123-142) */
-    int32_t n_boundary_cells;      /* > 0 with a q map enables Bouzidi (src/blocks.jl:152)          */
+    int32_t n_boundary_cells;      /* > 0 with a q map enables Bouzidi (src/blocks.jl:152); < 0: no cells here, but store
+                                      f_post_collision anyway (multi-GPU: a peer's Bouzidi cells read this rank's face layer) */
     const uint16_t *bouzidi_q_map; /* Float16 bits [8,8,8,nb,27]; optional                          */
     const int32_t  *bouzidi_cell_block;           /* [n_boundary_cells] 1-based                     */
     const int8_t   *bouzidi_cell_x, *bouzidi_cell_y, *bouzidi_cell_z;   /* 1-based local coords     */

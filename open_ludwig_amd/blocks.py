@@ -210,6 +210,8 @@ class DeviceLevel:
         h.wall_dist = ptr(host.wall_dist, np.float32) if (host.wall_dist != 100.0).any() else None
         h.enable_temporal_interpolation = 1 if host.f_old.size > 27 else 0
         h.n_boundary_cells = host.n_boundary_cells
+        if getattr(host, "force_post_collision", False) and host.n_boundary_cells == 0:
+            h.n_boundary_cells = -1        # multi-GPU: store f_post_collision although no Bouzidi cell is owned here
         if host.bouzidi_enabled:
             h.bouzidi_q_map = ptr(host.bouzidi_q_map.view(np.uint16))
             h.bouzidi_cell_block = ptr(host.bouzidi_cell_block, np.int32)
@@ -256,6 +258,10 @@ class DeviceLevel:
     @property
     def has_temporal_storage(self) -> bool:
         return bool(self.info().has_temporal_storage)
+
+    @property
+    def has_post_collision(self) -> bool:
+        return bool(self.info().has_post_collision)
 
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._lib.ludwig_level_set_stream(self.handle, C.c_void_p(hip_stream)))

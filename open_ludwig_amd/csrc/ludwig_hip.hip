@@ -359,7 +359,9 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     p.vel_in = L->vel[in];
     p.vel_out = L->vel[out];
     p.rho = L->rho;
-    p.f_post = (L->bouzidi_enabled && L->n_bc > 0) ? L->f_post : nullptr;   // reference src/physics_v2.jl:77
+    // reference src/physics_v2.jl:77: store_post_collision = bouzidi_enabled && n_boundary_cells > 0; a rank that owns no
+    // Bouzidi cell of a Bouzidi level still stores it when asked to (n_boundary_cells < 0): a peer's cells read its face layer
+    p.f_post = L->has_post ? L->f_post : nullptr;
     p.obstacle = L->obstacle;
     p.sponge = L->sponge;
     p.wall_dist = L->wall_dist;
@@ -519,7 +521,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     L->has_temporal = h->enable_temporal_interpolation && nb > 0;            // reference src/blocks.jl:123
     L->bouzidi_enabled = h->n_boundary_cells > 0 && h->bouzidi_q_map;        // reference src/blocks.jl:152
     L->n_bc = L->bouzidi_enabled ? h->n_boundary_cells : 0;
-    L->has_post = h->n_boundary_cells > 0 && nb > 0;                          // reference src/blocks.jl:135
+    L->has_post = h->n_boundary_cells != 0 && nb > 0;                         // reference src/blocks.jl:135 (< 0: forced, multi-GPU)
     if (L->bouzidi_enabled && (!h->bouzidi_cell_block || !h->bouzidi_cell_x || !h->bouzidi_cell_y || !h->bouzidi_cell_z)) {
         delete L;
         return fail(LUDWIG_ERR_INVALID, "bouzidi cell lists missing");

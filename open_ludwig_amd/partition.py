@@ -24,6 +24,7 @@ from .blocks import BLOCK_SIZE, BlockLevel, build_lattice_arrays, build_neighbor
 
 _CX, _CY, _CZ, _W, _OPP, _MY, _MZ = build_lattice_arrays()
 CELLS = 512
+FIELD_GROUPS = ("f", "vel", "f_post")      # logical halo fields: populations, velocity, post-collision populations
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -61,6 +62,36 @@ def build_local_level(level_id: int, coords: Sequence[Tuple[int, int, int]], nei
     cb[: len(owned)] = (table[: len(owned)] > len(owned)).any(axis=1)
     lvl.comm_boundary = cb
     return LocalView(rank, lvl, l2g, {int(g): i for i, g in enumerate(l2g)}, len(owned), owner[ghosts])
+
+
+def slice_level_fields(view: LocalView, source: BlockLevel) -> None:
+    """Fill a local level (owned + ghost blocks) from a populated GLOBAL host level: state, geometry, sponge, wall
+    distance and the Bouzidi data of the owned blocks (cell list re-indexed to local block ids)."""
+    lvl, g = view.level, view.local_to_global
+    for name in ("rho", "vel", "vel_temp", "f", "f_temp", "obstacle", "sponge", "wall_dist"):
+        getattr(lvl, name)[...] = getattr(source, name)[:, :, :, g]
+    if lvl.f_old.size > 27 and source.f_old.size > 27:
+        for name in ("f_old", "rho_old", "vel_old"):
+            getattr(lvl, name)[...] = getattr(source, name)[:, :, :, g]
+    if source.bouzidi_enabled:
+        g2l = np.full(source.n_blocks, -1, dtype=np.int64)
+        g2l[g[: view.n_owned]] = np.arange(view.n_owned)
+        lb = g2l[source.bouzidi_cell_block.astype(np.int64) - 1]
+        keep = lb >= 0
+        B = BLOCK_SIZE
+        lvl.bouzidi_q_map = np.asfortranarray(source.bouzidi_q_map[:, :, :, g])
+        lvl.bouzidi_cell_block = (lb[keep] + 1).astype(np.int32)
+        lvl.bouzidi_cell_x = source.bouzidi_cell_x[keep].copy()
+        lvl.bouzidi_cell_y = source.bouzidi_cell_y[keep].copy()
+        lvl.bouzidi_cell_z = source.bouzidi_cell_z[keep].copy()
+        lvl.n_boundary_cells = int(keep.sum())
+        lvl.bouzidi_enabled = lvl.n_boundary_cells > 0
+        # every rank of a Bouzidi level stores f_post_collision (its ghosts may be asked for it)
+        lvl.f_post_collision = np.zeros((B, B, B, lvl.n_blocks, 27), dtype=np.float32, order="F")
+        lvl.f_post_collision[...] = source.f_post_collision[:, :, :, g] if source.f_post_collision.size > 27 else 0.0
+        if lvl.n_boundary_cells == 0:
+            # keep the store of f_post_collision alive on this rank: a peer's Bouzidi cells may read our face layer
+            lvl.force_post_collision = True
 
 
 def _source_of(cx: int, cy: int, cz: int):
@@ -114,7 +145,31 @@ def compute_needs(view: LocalView) -> Dict[str, np.ndarray]:
                     out_v.append((comp * nb + blk0) * CELLS + cells)
     f = np.unique(np.concatenate(out_f)) if out_f else np.zeros(0, np.int64)
     v = np.unique(np.concatenate(out_v)) if out_v else np.zeros(0, np.int64)
-    return {"f": f, "vel": v}
+    needs = {"f": f, "vel": v}
+    if lvl.bouzidi_enabled and lvl.n_boundary_cells > 0:
+        # Bouzidi q < 1/2 reads f_post_collision[k] at cell + c_opp(k) (src/bouzidi_kernel.jl:44-77); across a cut that
+        # cell lives in a ghost block. All 0 < q < 1/2 links are listed (a superset of q > q_min: harmless).
+        B = BLOCK_SIZE
+        cb = lvl.bouzidi_cell_block.astype(np.int64) - 1
+        x = lvl.bouzidi_cell_x.astype(np.int64) - 1; y = lvl.bouzidi_cell_y.astype(np.int64) - 1; z = lvl.bouzidi_cell_z.astype(np.int64) - 1
+        out_p: List[np.ndarray] = []
+        full_table = np.asarray(lvl.neighbor_table)
+        for k in range(27):
+            q = lvl.bouzidi_q_map[x, y, z, cb, k].astype(np.float32)
+            m = (q > 0) & (q < 0.5)
+            if not m.any():
+                continue
+            ok = int(_OPP[k]) - 1
+            nx, ny, nz = x[m] + int(_CX[ok]), y[m] + int(_CY[ok]), z[m] + int(_CZ[ok])
+            ox = np.where(nx < 0, -1, np.where(nx >= B, 1, 0)); oy = np.where(ny < 0, -1, np.where(ny >= B, 1, 0)); oz = np.where(nz < 0, -1, np.where(nz >= B, 1, 0))
+            d = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1)
+            nbl = full_table[cb[m], d].astype(np.int64)          # 1-based local id
+            gh = nbl > n_owned
+            if gh.any():
+                cell = (nx[gh] % B) + B * (ny[gh] % B) + B * B * (nz[gh] % B)
+                out_p.append((k * nb + nbl[gh] - 1) * CELLS + cell)
+        needs["f_post"] = np.unique(np.concatenate(out_p)) if out_p else np.zeros(0, np.int64)
+    return needs
 
 
 def _to_global(view: LocalView, local_off: np.ndarray, n_global: int) -> np.ndarray:
@@ -146,6 +201,9 @@ class HaloPlan:
     def bytes_per_step(self) -> int:
         return 4 * sum(a.size for p in self.peers for a in self.send[p].values())
 
+    def has(self, name: str) -> bool:
+        return any(self.send[p][name].size or self.recv[p][name].size for p in self.peers)
+
 
 def make_requests(view: LocalView, n_global: int) -> Dict[int, Dict[str, np.ndarray]]:
     """What this rank asks of every peer: global element offsets, sorted; also fills nothing else."""
@@ -161,7 +219,7 @@ def make_requests(view: LocalView, n_global: int) -> Dict[int, Dict[str, np.ndar
             o = np.argsort(g, kind="stable")
             req.setdefault(int(p), {})[name] = g[o]
     for p in req:
-        for name in ("f", "vel"):
+        for name in FIELD_GROUPS:
             req[p].setdefault(name, np.zeros(0, np.int64))
     return req
 
@@ -176,7 +234,7 @@ def build_plan(view: LocalView, n_global: int, my_requests: Dict[int, Dict[str, 
     for p in plan.peers:
         plan.recv[p] = {}
         plan.send[p] = {}
-        for name in ("f", "vel"):
+        for name in FIELD_GROUPS:
             g = my_requests.get(p, {}).get(name, np.zeros(0, np.int64))
             comp, rem = np.divmod(g, n_global * CELLS)
             gblk, cell = np.divmod(rem, CELLS)
@@ -205,7 +263,7 @@ class HaloExchanger:
         self.pack, self.unpack = pack, unpack
         self.stage = stage_through_host
         self.idx_send, self.idx_recv, self.buf_send, self.buf_recv, self.seg_send, self.seg_recv = {}, {}, {}, {}, {}, {}
-        for name in ("f", "vel"):
+        for name in FIELD_GROUPS:
             s_lists = [plan.send[p][name] for p in plan.peers]
             r_lists = [plan.recv[p][name] for p in plan.peers]
             cat = lambda ls: np.concatenate(ls) if ls else np.zeros(0, np.int64)
@@ -218,26 +276,34 @@ class HaloExchanger:
             self.seg_send[name] = {p: (int(so[i]), int(so[i + 1])) for i, p in enumerate(plan.peers)}
             self.seg_recv[name] = {p: (int(ro[i]), int(ro[i + 1])) for i, p in enumerate(plan.peers)}
         if self.stage:
-            self.host_send = {n: torch.empty(self.buf_send[n].numel(), dtype=torch.float32).pin_memory() for n in ("f", "vel")}
-            self.host_recv = {n: torch.empty(self.buf_recv[n].numel(), dtype=torch.float32).pin_memory() for n in ("f", "vel")}
+            self.host_send = {n: torch.empty(self.buf_send[n].numel(), dtype=torch.float32).pin_memory() for n in FIELD_GROUPS}
+            self.host_recv = {n: torch.empty(self.buf_recv[n].numel(), dtype=torch.float32).pin_memory() for n in FIELD_GROUPS}
 
     def exchange(self, f_name: str, vel_name: str) -> None:
         """Refresh the ghost elements of fields `f_name` ('f' | 'f_temp') and `vel_name` ('vel' | 'vel_temp')."""
+        self.exchange_fields({"f": f_name, "vel": vel_name})
+
+    def exchange_post_collision(self) -> None:
+        """Refresh the ghost elements of f_post_collision that Bouzidi cells next to a partition cut read."""
+        self.exchange_fields({"f_post": "f_post_collision"})
+
+    def exchange_fields(self, fields: Dict[str, str]) -> None:
+        """fields: logical halo group ('f' | 'vel' | 'f_post') -> name of the level field to move."""
         import torch.distributed as dist
         torch = self.torch
-        fields = {"f": f_name, "vel": vel_name}
-        for n in ("f", "vel"):
+        names = tuple(fields)
+        for n in names:
             if self.buf_send[n].numel():
                 self.pack(fields[n], self.idx_send[n], self.buf_send[n])
         if self.stage:
-            for n in ("f", "vel"):
+            for n in names:
                 self.host_send[n].copy_(self.buf_send[n], non_blocking=True)
             torch.cuda.current_stream().synchronize()
         snd = self.host_send if self.stage else self.buf_send
         rcv = self.host_recv if self.stage else self.buf_recv
         ops = []
         for p in self.plan.peers:
-            for n in ("f", "vel"):
+            for n in names:
                 a, b = self.seg_send[n][p]
                 c, d = self.seg_recv[n][p]
                 if p == self.rank:
@@ -252,9 +318,9 @@ class HaloExchanger:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if self.stage:
-            for n in ("f", "vel"):
+            for n in names:
                 self.buf_recv[n].copy_(self.host_recv[n], non_blocking=True)
-        for n in ("f", "vel"):
+        for n in names:
             if self.buf_recv[n].numel():
                 self.unpack(fields[n], self.idx_recv[n], self.buf_recv[n])
 
@@ -352,6 +418,26 @@ class DistributedLevelRunner:
         out_f, out_v = ("f_temp", "vel_temp") if t % 2 == 0 else ("f", "vel")
         if self._have_exchange:
             self.s_comp.wait_event(self.ev_exchanged)       # ghosts of this step's input are in place
+        if self.level.has_post_collision:
+            # Bouzidi level: the correction rewrites f_out at boundary cells AFTER the collision and reads the post-collision
+            # populations of neighbour cells, so: collide everything -> f_post halo -> correction -> f / u halo (no overlap)
+            from .physics import apply_bouzidi_correction
+            stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_ALL)
+            with torch.cuda.stream(self.s_comm):
+                self.ev_boundary.record(self.s_comp)
+                self.s_comm.wait_event(self.ev_boundary)
+                if self.ex.plan.has("f_post"):
+                    self.ex.exchange_post_collision()
+                self.ev_exchanged.record(self.s_comm)
+            self.s_comp.wait_event(self.ev_exchanged)
+            apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
+            with torch.cuda.stream(self.s_comm):
+                self.ev_boundary.record(self.s_comp)
+                self.s_comm.wait_event(self.ev_boundary)
+                self.ex.exchange(out_f, out_v)
+                self.ev_exchanged.record(self.s_comm)
+            self._have_exchange = True
+            return
         if not self.overlap:
             stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_ALL)
             self.ex.exchange(out_f, out_v)
@@ -367,6 +453,19 @@ class DistributedLevelRunner:
 
     def synchronize(self) -> None:
         self.torch.cuda.synchronize(self.dev)
+
+
+def distributed_level(global_level: BlockLevel, owner: np.ndarray, params, rank: int, world: int, device: int, overlap: bool = True,
+                      stage_through_host: bool = False) -> "DistributedLevelRunner":
+    """Partition a populated single-level case (any topology: tunnel with body, sponge, Bouzidi ...) by the block owner map."""
+    view = build_local_level(global_level.level_id, global_level.active_block_coords, global_level.neighbor_table, owner, rank,
+                             float(global_level.tau), temporal=global_level.f_old.size > 27)
+    slice_level_fields(view, global_level)
+    n_global = global_level.n_blocks
+    mine = make_requests(view, n_global)
+    to_me = exchange_requests(mine, world, rank) if world > 1 else {}
+    plan = build_plan(view, n_global, mine, to_me)
+    return DistributedLevelRunner(view, plan, params, device, overlap=overlap, stage_through_host=stage_through_host)
 
 
 def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int, int], device: int, overlap: bool = True,

@@ -52,6 +52,19 @@ def main():
             oracle.execute_timestep_batch([lvl], t, 1, np.float32(0.0), params)
             ex.exchange(*(("f_temp", "vel_temp") if t % 2 == 0 else ("f", "vel")))
         res = {n: getattr(lvl, n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
+    elif mode == "gpu_tunnel":
+        # single-level tunnel with sphere, sponge, Bouzidi cells on both sides of the cut; split along x
+        grids, params = cases.tunnel_with_sphere(nbg, levels=1, wall_model=False, temporal=False)
+        g = grids[0]
+        bx = np.asarray(g.active_block_coords)[:, 0]
+        owner = ((bx - 1) * world // nbx).astype(np.int64)
+        runner = partition.distributed_level(g, owner, params, rank, world, device=0, overlap=bool(overlap), stage_through_host=True)
+        view = runner.view
+        for t in range(1, steps + 1):
+            runner.step(t, np.float32(0.05))
+        runner.synchronize()
+        res = {n: runner.level.download(n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
+        res["nbc"] = np.array([runner.level.n_boundary_cells, int(runner.ex.plan.has("f_post"))])
     else:
         per = tuple(nbg[i] // grid[i] for i in range(3))
         runner = partition.periodic_weak_scaling_box(rank, world, per, device=0, overlap=bool(overlap), stage_through_host=True)

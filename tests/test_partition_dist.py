@@ -64,3 +64,23 @@ def test_four_ranks_one_gpu_hip_path(tmp_path, gpu):
     nbg, steps = (4, 4, 4), 3
     _launch("gpu", tmp_path, nbg, steps, world=4)
     _check(tmp_path, nbg, steps, 4)
+
+
+@pytest.mark.gpu
+def test_two_ranks_tunnel_with_bouzidi_across_the_cut(tmp_path, gpu):
+    """Non-periodic tunnel (inlet/outlet/mirror edges, sponge, obstacle) cut through the sphere: Bouzidi cells on both
+    ranks, f_post_collision exchanged between collision and correction. Owned blocks must equal the single-domain oracle."""
+    nbg, steps = (8, 4, 4), 3
+    _launch("gpu_tunnel", tmp_path, nbg, steps, world=2)
+    grids, params = cases.tunnel_with_sphere(nbg, levels=1, wall_model=False, temporal=False)
+    oracle.execute_timestep_batch(grids, 1, steps, np.float32(0.05), params)
+    fn, vn = oracle.newest_buffers(0, steps)
+    both_have_cells, used_post_halo = [], []
+    for r in range(2):
+        d = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        for name in (fn, vn, "rho"):
+            assert np.array_equal(d[name], getattr(grids[0], name)[:, :, :, d["l2g"]]), f"rank {r} {name}"
+        both_have_cells.append(int(d["nbc"][0]) > 0)
+        used_post_halo.append(bool(d["nbc"][1]))
+    assert all(both_have_cells), "the cut was meant to pass through the Bouzidi cells"
+    assert any(used_post_halo), "no f_post_collision element crossed the cut: the test does not exercise the exchange"
