@@ -334,6 +334,20 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
                                             const float ux_N, const float uy_N, const float uz_N, const float ux_S, const float uy_S, const float uz_S,
                                             const float ux_T, const float uy_T, const float uz_T, const float ux_B, const float uy_B, const float uz_B)
 {
+#ifdef LW_DIAG_NO_MATH   // timing-only diagnostic build: same loads and stores, no collision arithmetic; results are wrong
+    {
+        float acc = ux_E + uy_E + uz_E + ux_W + uy_W + uz_W + ux_N + uy_N + uz_N + ux_S + uy_S + uz_S + ux_T + uy_T + uz_T + ux_B + uy_B + uz_B;
+        st_f32(p.vel_out, own_bytes, acc);
+        st_f32(p.vel_out + p.sk, own_bytes, fs[1]);
+        st_f32(p.vel_out + 2 * p.sk, own_bytes, fs[2]);
+        st_f32(p.rho, own_bytes, fs[0]);
+        static_for<0, Q>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            st_f32(p.f_out + p.sk * k, own_bytes, fs[k]);
+        });
+        return;
+    }
+#endif
     // moments in the reference's order: rho += f_k; j += f_k * c_k for k = 1..27
     float rho = 0.0f, jx = 0.0f, jy = 0.0f, jz = 0.0f;
     static_for<0, Q>([&](auto kc) {
@@ -614,7 +628,11 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     float halo[Q];                                            // outer-face column (first / last wave only)
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
+#ifdef LW_DIAG_NO_YSHIFT   // timing-only
+        constexpr int cx = CX(k), cy = 0, g = 1 - CZ(k);
+#else
         constexpr int cx = CX(k), cy = CY(k), g = 1 - CZ(k);
+#endif
         const bool yo = cy == 1 ? l.y0 : (cy == -1 ? l.y7 : false);
         const int c00 = nbr.id[g][4], cY = nbr.id[g][4 - 3 * cy];
         const int sel = cy != 0 ? (yo ? cY : c00) : c00;
@@ -623,7 +641,11 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         fs[k] = ld_f32(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
         halo[k] = 0.0f;
         if constexpr (cx != 0) {
+#ifdef LW_DIAG_NO_OUTER   // timing-only
+            if (false) {
+#else
             if (cx == 1 ? first : last) {                     // the run's outer face: strided column of the x / xy neighbour
+#endif
                 const int cX = nbr.id[g][4 - cx], cXY = nbr.id[g][4 - cx - 3 * cy];
                 const int selx = cy != 0 ? (yo ? cXY : cX) : cX;
                 if (cx == 1 ? l.x0 : l.x7)
@@ -646,6 +668,16 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float *vc = p.vel_in + p.sk * c;
+#if defined(LW_DIAG_NO_VEL)   // timing-only
+            uc[c] = __int_as_float(own_bytes + c); uT[c] = uc[c]; uB[c] = uc[c]; uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
+            (void)vc; (void)offT; (void)offB; (void)offY; (void)offXlo; (void)offXhi;
+#elif defined(LW_DIAG_NO_VEL_TB)
+            uc[c] = ld_f32(vc, own_bytes); uT[c] = uc[c]; uB[c] = uc[c];
+            uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
+            if (l.y0 || l.y7) uy_edge[c] = ld_f32(vc, offY);
+            if (first) { if (l.x0) ux_edge_lo[c] = ld_f32(vc, offXlo); }
+            if (last) { if (l.x7) ux_edge_hi[c] = ld_f32(vc, offXhi); }
+#else
             uc[c] = ld_f32(vc, own_bytes);
             uT[c] = ld_f32(vc, offT);
             uB[c] = ld_f32(vc, offB);
@@ -653,6 +685,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
             if (l.y0 || l.y7) uy_edge[c] = ld_f32(vc, offY);
             if (first) { if (l.x0) ux_edge_lo[c] = ld_f32(vc, offXlo); }
             if (last) { if (l.x7) ux_edge_hi[c] = ld_f32(vc, offXhi); }
+#endif
         }
     }
 
