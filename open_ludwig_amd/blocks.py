@@ -224,6 +224,8 @@ class DeviceLevel:
         _lib.check(lib.ludwig_level_create(C.byref(h), device, C.byref(handle)))
         self._h = handle
         # state: the constructor defaults already match; copy whatever the host level holds
+        if self.n_blocks == 0:
+            return
         for name in ("f", "f_temp", "rho", "vel", "vel_temp"):
             self.upload(name, getattr(host, name))
         if self.has_temporal_storage:
