@@ -85,3 +85,33 @@ def test_hip_matches_oracle_on_ball1m(gpu, ball_setup):
         a, b = getattr(hip[0], name), getattr(ora[0], name)
         assert abs(a - b) <= 1e-5 * abs(b), (name, a, b)
     assert abs(hip[0].cl - ora[0].cl) <= 1e-5 * abs(ora[0].cd)      # Cl ~ 0 here: scale by Cd
+
+
+# ---- BASELINE configs[0]: cube1m as a single-level ~64^3 case, "BGK only" (c_wale = 0, nu_sgs_background = 0) ----
+CUBE = {"basic": {"num_levels": 1, "surface_resolution": 7},
+        "advanced": {"boundary": {"method": "bounce_back"}, "high_re": {"wall_model": {"enabled": False}},
+                     "numerics": {"c_wale": 0.0, "nu_sgs_background": 0.0}, "diagnostics": {"freq": 16}}}
+
+
+def test_cube1m_setup_is_the_72x64x64_tunnel():
+    """num_levels 1 + surface_resolution 7 gives a 72 x 64 x 64 level-1 tunnel (9.25 x 8.5 x 8.5 m domain)."""
+    cfg = pp.load_case_configuration(os.path.join(G, "cube1m_config.yaml"), CUBE)
+    grids, mesh, params, rep = pp.setup_multilevel_domain(cfg, os.path.join(G, "cube1m.stl"))
+    assert mesh.triangles.shape[0] == 12 and params.num_levels == 1
+    assert (params.nx_coarse, params.ny_coarse, params.nz_coarse) == (72, 64, 64) and rep.level_blocks == [576]
+    assert not grids[0].bouzidi_enabled and int(grids[0].obstacle.sum()) == 576       # SAT shell (0.75 dx half-box) + 180 filled
+    assert (grids[0].wall_dist == 100).all()
+
+
+@pytest.mark.gpu
+def test_cube1m_hip_equals_oracle(gpu):
+    from _steppers import OracleStepper
+    from oracle import oracle
+    oracle.set_num_threads(16)
+    cfg = pp.load_case_configuration(os.path.join(G, "cube1m_config.yaml"), CUBE)
+    stl = os.path.join(G, "cube1m.stl")
+    hip, _, _ = case.run_case(cfg, case.HipStepper, steps=48, setup=pp.setup_multilevel_domain(cfg, stl))
+    ora, _, _ = case.run_case(cfg, OracleStepper, steps=48, setup=pp.setup_multilevel_domain(cfg, stl))
+    assert [r.step for r in hip] == [16, 32, 48] == [r.step for r in ora]
+    for a, b in zip(hip, ora):
+        assert a.rho_min == b.rho_min and a.cd == b.cd and a.cl == b.cl, (a, b)      # bounce-back, no wall model: exact

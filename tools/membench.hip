@@ -323,6 +323,27 @@ __global__ __launch_bounds__(256) void k_pull_x(const float *__restrict__ in, fl
     *(float *)((char *)out + own) = s;
 }
 
+
+// N: aligned plane copy with non-temporal loads and/or stores
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_plane_copy_nt(const float *__restrict__ in, float *__restrict__ out, const int *__restrict__ items, size_t sk)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = items[blockIdx.x * 4 + wave];
+    const uint32_t off = ((uint32_t)(item >> 3) * 512u + (uint32_t)(item & 7) * 64u + (threadIdx.x & 63)) * 4u;
+    float v[Q];
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const float *p = (const float *)((const char *)(in + sk * k) + off);
+        v[k] = NTL ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        float *p = (float *)((char *)(out + sk * k) + off);
+        if (NTS) __builtin_nontemporal_store(v[k], p); else *p = v[k];
+    }
+}
+
 // write-only, plane per wave
 __global__ __launch_bounds__(256) void k_plane_write(float *__restrict__ out, const int *__restrict__ items, size_t sk)
 {
@@ -470,5 +491,11 @@ int main(int argc, char **argv)
     report("X mode0 misaligned rows only", T.run([&] { hipLaunchKernelGGL((k_pull_x<0>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk, NB); }, 7), 112);
     report("X mode1 neighbour column only", T.run([&] { hipLaunchKernelGGL((k_pull_x<1>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk, NB); }, 7), 112);
     report("X mode2 real x pull", T.run([&] { hipLaunchKernelGGL((k_pull_x<2>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk, NB); }, 7), 112);
+
+    report("N copy plain", T.run([&] { hipLaunchKernelGGL((k_plane_copy_nt<false, false>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk); }, 9), 216);
+    report("N copy nt loads", T.run([&] { hipLaunchKernelGGL((k_plane_copy_nt<true, false>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk); }, 9), 216);
+    report("N copy nt stores", T.run([&] { hipLaunchKernelGGL((k_plane_copy_nt<false, true>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk); }, 9), 216);
+    report("N copy nt both", T.run([&] { hipLaunchKernelGGL((k_plane_copy_nt<true, true>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk); }, 9), 216);
+    report("N copy plain (again)", T.run([&] { hipLaunchKernelGGL((k_plane_copy_nt<false, false>), dim3(gw), dim3(256), 0, 0, in, out, d_nat, sk); }, 9), 216);
     return 0;
 }
