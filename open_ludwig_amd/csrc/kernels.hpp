@@ -235,6 +235,15 @@ __device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off)
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 #endif
 }
+// load of a line that has exactly ONE reader in the launch (non-temporal: do not keep it in L2 / Infinity Cache)
+__device__ __forceinline__ float ld_f32_once(const float *base, uint32_t byte_off)
+{
+#ifdef LW_NT_SINGLE_READER
+    return __builtin_nontemporal_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off));
+#else
+    return ld_f32(base, byte_off);
+#endif
+}
 __device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v)
 {
 #ifdef LW_NT_STORES
@@ -638,7 +647,10 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         const int sel = cy != 0 ? (yo ? cY : c00) : c00;
         const uint32_t rowz = (uint32_t)((8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(nbr.zs[g] * 256);
         const float *fk = p.f_in + p.sk * k;
-        fs[k] = ld_f32(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
+        // populations with cy = 0: the two lines of this plane are read by this wave only (the x neighbours get their
+        // column through LDS, nobody shifts rows) -> single reader
+        if constexpr (cy == 0) fs[k] = ld_f32_once(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
+        else fs[k] = ld_f32(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
         halo[k] = 0.0f;
         if constexpr (cx != 0) {
 #ifdef LW_DIAG_NO_OUTER   // timing-only

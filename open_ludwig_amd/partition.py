@@ -24,7 +24,7 @@ from .blocks import BLOCK_SIZE, BlockLevel, build_lattice_arrays, build_neighbor
 
 _CX, _CY, _CZ, _W, _OPP, _MY, _MZ = build_lattice_arrays()
 CELLS = 512
-FIELD_GROUPS = ("f", "vel", "f_post")      # logical halo fields: populations, velocity, post-collision populations
+FIELD_GROUPS = ("f", "vel", "f_post", "rho")   # logical halo fields: populations, velocity, post-collision populations, density
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -205,9 +205,10 @@ class HaloPlan:
         return any(self.send[p][name].size or self.recv[p][name].size for p in self.peers)
 
 
-def make_requests(view: LocalView, n_global: int) -> Dict[int, Dict[str, np.ndarray]]:
-    """What this rank asks of every peer: global element offsets, sorted; also fills nothing else."""
-    needs = compute_needs(view)
+def make_requests(view: LocalView, n_global: int, needs: Optional[Dict[str, np.ndarray]] = None) -> Dict[int, Dict[str, np.ndarray]]:
+    """What this rank asks of every peer: global element offsets, sorted."""
+    if needs is None:
+        needs = compute_needs(view)
     nb, n_owned = view.level.n_blocks, view.n_owned
     req: Dict[int, Dict[str, np.ndarray]] = {}
     for name, off in needs.items():
@@ -466,6 +467,158 @@ def distributed_level(global_level: BlockLevel, owner: np.ndarray, params, rank:
     to_me = exchange_requests(mine, world, rank) if world > 1 else {}
     plan = build_plan(view, n_global, mine, to_me)
     return DistributedLevelRunner(view, plan, params, device, overlap=overlap, stage_through_host=stage_through_host)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# multi-level (scope row N3): every level partitioned by the owner of its level-1 ancestor, parent-data ghosts
+# ----------------------------------------------------------------------------------------------------------------
+def ancestor_owner(level_id: int, coords, level1_coords, level1_owner: np.ndarray) -> np.ndarray:
+    """owner of a level-l block = owner of the level-1 block that contains it (block coords shrink by 2 per level)"""
+    lut = {tuple(c): int(o) for c, o in zip(np.asarray(level1_coords), level1_owner)}
+    c = (np.asarray(coords, dtype=np.int64) - 1) >> (level_id - 1)
+    return np.array([lut[(int(a) + 1, int(b) + 1, int(d) + 1)] for a, b, d in c], dtype=np.int64)
+
+
+def interpolation_needs(child: LocalView, parent: LocalView, domain_cells: Tuple[int, int, int]) -> Dict[str, np.ndarray]:
+    """Parent-level ghost elements the child's coarse->fine interface reads (src/physics_interpolation.jl:29-62):
+    for every link (owned child cell, k) whose source block is missing and whose source cell lies inside the global box,
+    the 8 parent cells around the source position; f_k, rho and the 3 velocity components of those that live in parent
+    GHOST blocks. Offsets are local to the parent level (reference layout)."""
+    B = BLOCK_SIZE
+    cl, pl = child.level, parent.level
+    scale = 2 ** (cl.level_id - 1)
+    nxg, nyg, nzg = (d * scale for d in domain_cells)
+    table = np.asarray(cl.neighbor_table)[: child.n_owned]
+    edge = np.flatnonzero((table == 0).any(axis=1))
+    out = {"f": [], "rho": [], "vel": []}
+    if edge.size == 0:
+        return {k: np.zeros(0, np.int64) for k in out}
+    bx = cl.map_x[edge].astype(np.int64); by = cl.map_y[edge].astype(np.int64); bz = cl.map_z[edge].astype(np.int64)
+    pnb = pl.n_blocks
+    pptr = np.asarray(pl.block_pointer)
+    pdx, pdy, pdz = pptr.shape
+    x, y, z = np.meshgrid(np.arange(B), np.arange(B), np.arange(B), indexing="ij")
+    x, y, z = x.reshape(-1), y.reshape(-1), z.reshape(-1)
+    for k in range(27):
+        cx, cy, cz = int(_CX[k]), int(_CY[k]), int(_CZ[k])
+        sx, sy, sz = x - cx, y - cy, z - cz
+        ox = np.where(sx < 0, -1, np.where(sx >= B, 1, 0)); oy = np.where(sy < 0, -1, np.where(sy >= B, 1, 0)); oz = np.where(sz < 0, -1, np.where(sz >= B, 1, 0))
+        cross = np.flatnonzero((ox != 0) | (oy != 0) | (oz != 0))
+        if cross.size == 0:
+            continue
+        d = (ox + 1) + 3 * (oy + 1) + 9 * (oz + 1)
+        missing = table[edge][:, d[cross]] == 0                                   # [n_edge, n_cross]
+        gx = ((bx - 1) * B)[:, None] + x[cross][None, :] + 1 - cx                  # source cell, 1-based fine coords
+        gy = ((by - 1) * B)[:, None] + y[cross][None, :] + 1 - cy
+        gz = ((bz - 1) * B)[:, None] + z[cross][None, :] + 1 - cz
+        inside = (gx >= 1) & (gx <= nxg) & (gy >= 1) & (gy <= nyg) & (gz >= 1) & (gz <= nzg)
+        m = missing & inside
+        if not m.any():
+            continue
+        sgx, sgy, sgz = gx[m], gy[m], gz[m]
+        pc = [((s.astype(np.float32) - np.float32(0.5)) * np.float32(0.5)) for s in (sgx, sgy, sgz)]
+        p0 = [np.floor(v).astype(np.int64) for v in pc]
+        p1 = [v + 1 for v in p0]
+        p0 = [np.maximum(v, 1) for v in p0]                                        # px1 before the clamp (Appendix A.14)
+        for n in range(8):
+            pg = [(p1[a] if (n >> a) & 1 else p0[a]) for a in range(3)]
+            pb = [(v - 1) // B + 1 for v in pg]
+            ok = (pb[0] >= 1) & (pb[0] <= pdx) & (pb[1] >= 1) & (pb[1] <= pdy) & (pb[2] >= 1) & (pb[2] <= pdz)
+            idx = np.zeros(len(sgx), dtype=np.int64)
+            idx[ok] = pptr[pb[0][ok] - 1, pb[1][ok] - 1, pb[2][ok] - 1]
+            gh = idx > parent.n_owned                                              # lives in a parent ghost block
+            if not gh.any():
+                continue
+            cell = ((pg[0][gh] - 1) % B) + B * ((pg[1][gh] - 1) % B) + B * B * ((pg[2][gh] - 1) % B)
+            blk0 = idx[gh] - 1
+            out["f"].append((k * pnb + blk0) * CELLS + cell)
+            out["rho"].append(blk0 * CELLS + cell)
+            for comp in range(3):
+                out["vel"].append((comp * pnb + blk0) * CELLS + cell)
+    return {k: (np.unique(np.concatenate(v)) if v else np.zeros(0, np.int64)) for k, v in out.items()}
+
+
+class MultiLevelRunner:
+    """Distributed recursive_step! (src/solver_control.jl:21-143) for nested levels: same call order and A/B parity as
+    the single-device driver, plus after every level step the halo exchange of that level (same-level ghosts AND the
+    parent-data ghosts its children interpolate from). Levels are small here, so the exchange is not overlapped."""
+
+    def __init__(self, grids: Sequence[BlockLevel], owner_level1: np.ndarray, params, rank: int, world: int, device: int,
+                 stage_through_host: bool = False):
+        import ctypes as C
+        import torch
+        from . import _lib
+        from .blocks import adapt
+        self.params, self.rank, self.world = params, rank, world
+        self.torch, self._lib = torch, _lib
+        dims = (params.domain_nx, params.domain_ny, params.domain_nz)
+        self.views: List[LocalView] = []
+        for g in grids:
+            own = owner_level1 if g.level_id == 1 else ancestor_owner(g.level_id, g.active_block_coords, grids[0].active_block_coords, owner_level1)
+            v = build_local_level(g.level_id, g.active_block_coords, g.neighbor_table, own, rank, float(g.tau), temporal=g.f_old.size > 27)
+            slice_level_fields(v, g)
+            self.views.append(v)
+        # a rank that owns nothing of a (fine) level keeps no device level for it and skips it in the recursion
+        self.levels = [adapt(v.level, device) if v.n_owned > 0 else None for v in self.views]
+        self.dev = torch.device("cuda", device)
+        lib = _lib.load()
+        self.ex: List[HaloExchanger] = []
+        for i, (v, g) in enumerate(zip(self.views, grids)):
+            needs = compute_needs(v)
+            needs.setdefault("f_post", np.zeros(0, np.int64))
+            needs.setdefault("rho", np.zeros(0, np.int64))
+            if i + 1 < len(grids):
+                extra = interpolation_needs(self.views[i + 1], v, dims)
+                for name in ("f", "rho", "vel"):
+                    needs[name] = np.unique(np.concatenate([needs[name], extra[name]]))
+            mine = make_requests(v, g.n_blocks, needs)
+            to_me = exchange_requests(mine, world, rank) if world > 1 else {}
+            plan = build_plan(v, g.n_blocks, mine, to_me)
+            handle = self.levels[i].handle if self.levels[i] is not None else None
+
+            def pack(name, idx, out, handle=handle):
+                _lib.check(lib.ludwig_halo_pack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+
+            def unpack(name, idx, src, handle=handle):
+                _lib.check(lib.ludwig_halo_unpack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
+                                                  C.c_void_p(src.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+
+            self.ex.append(HaloExchanger(plan, rank, self.dev, pack, unpack, stage_through_host))
+
+    def _step_level(self, i: int, t_sub: int, parent, parent_tau, tw, u) -> None:
+        from .physics import apply_bouzidi_correction, stream_collide
+        _lib = self._lib
+        L, ex = self.levels[i], self.ex[i]
+        out_f, out_v = ("f_temp", "vel_temp") if t_sub % 2 == 0 else ("f", "vel")
+        stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
+        if L.has_post_collision:
+            if ex.plan.has("f_post"):
+                ex.exchange_post_collision()
+            apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
+        fields = {"f": out_f, "vel": out_v}
+        if ex.plan.has("rho"):
+            fields["rho"] = "rho"
+        ex.exchange_fields(fields)
+
+    def _rec(self, lvl: int, t_sub: int, parent, parent_tau, tw, u) -> None:
+        if lvl > len(self.levels) or self.levels[lvl - 1] is None:
+            return
+        L = self.levels[lvl - 1]
+        has_children = lvl < len(self.levels) and self.levels[lvl] is not None
+        if has_children and self.params.use_temporal_interp and L.has_temporal_storage:
+            L.copy_to_old(t_sub)
+        self._step_level(lvl - 1, t_sub, parent, parent_tau, tw, u)
+        if has_children:
+            self._rec(lvl + 1, 2 * t_sub, L, L.tau, np.float32(0.0), u)
+            self._rec(lvl + 1, 2 * t_sub + 1, L, L.tau, np.float32(0.5), u)
+
+    def step(self, t: int, u_curr=0.0) -> None:
+        """one coarse step = recursive_step!(grids, 1, t, ...)"""
+        self._rec(1, t, None, np.float32(0.5), np.float32(0.0), np.float32(u_curr))
+
+    def synchronize(self) -> None:
+        self.torch.cuda.synchronize(self.dev)
 
 
 def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int, int], device: int, overlap: bool = True,

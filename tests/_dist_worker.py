@@ -65,6 +65,33 @@ def main():
         runner.synchronize()
         res = {n: runner.level.download(n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
         res["nbc"] = np.array([runner.level.n_boundary_cells, int(runner.ex.plan.has("f_post"))])
+    elif mode == "gpu_multilevel":
+        # nested levels (interface interpolation from parent-data ghosts, temporal blend, Bouzidi sphere), split along x
+        levels, wall = overlap & 7, bool(overlap & 8)
+        grids, params = cases.tunnel_with_sphere(nbg, levels=levels, wall_model=wall, temporal=True)
+        bx = np.asarray(grids[0].active_block_coords)[:, 0]
+        owner1 = ((bx - 1) * world // nbx).astype(np.int64)
+        runner = partition.MultiLevelRunner(grids, owner1, params, rank, world, device=0, stage_through_host=True)
+        for t in range(1, steps + 1):
+            runner.step(t, np.float32(0.05))
+        runner.synchronize()
+        from oracle import oracle as _o   # only for the buffer-parity helper
+        res = {}
+        for i, (lv, v) in enumerate(zip(runner.levels, runner.views)):
+            f_name, v_name = _o.newest_buffers(i, steps)
+            res[f"l2g{i}"] = v.local_to_global[: v.n_owned]
+            if lv is None:
+                res[f"f{i}"], res[f"vel{i}"], res[f"rho{i}"] = np.zeros((8, 8, 8, 0, 27), np.float32), np.zeros((8, 8, 8, 0, 3), np.float32), np.zeros((8, 8, 8, 0), np.float32)
+                res[f"stats{i}"] = np.array([0, 0, 0, 0])
+                continue
+            res[f"f{i}"] = lv.download(f_name)[:, :, :, : v.n_owned]
+            res[f"vel{i}"] = lv.download(v_name)[:, :, :, : v.n_owned]
+            res[f"rho{i}"] = lv.download("rho")[:, :, :, : v.n_owned]
+            res[f"stats{i}"] = np.array([v.n_owned, v.level.n_blocks, runner.ex[i].plan.bytes_per_step(), int(runner.ex[i].plan.has("rho"))])
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     else:
         per = tuple(nbg[i] // grid[i] for i in range(3))
         runner = partition.periodic_weak_scaling_box(rank, world, per, device=0, overlap=bool(overlap), stage_through_host=True)

@@ -84,3 +84,44 @@ def test_two_ranks_tunnel_with_bouzidi_across_the_cut(tmp_path, gpu):
         used_post_halo.append(bool(d["nbc"][1]))
     assert all(both_have_cells), "the cut was meant to pass through the Bouzidi cells"
     assert any(used_post_halo), "no f_post_collision element crossed the cut: the test does not exercise the exchange"
+
+
+def _check_multilevel(outdir, nbg, steps, levels, wall, world, rtol=0.0):
+    grids, params = cases.tunnel_with_sphere(nbg, levels=levels, wall_model=wall, temporal=True)
+    oracle.execute_timestep_batch(grids, 1, steps, np.float32(0.05), params)
+    cut_levels = 0
+    for i, g in enumerate(grids):
+        fn, vn = oracle.newest_buffers(i, steps)
+        seen, ghosts = 0, 0
+        for r in range(world):
+            d = np.load(os.path.join(outdir, f"rank{r}.npz"))
+            l2g = d[f"l2g{i}"]
+            for got, name in ((d[f"f{i}"], fn), (d[f"vel{i}"], vn), (d[f"rho{i}"], "rho")):
+                want = getattr(g, name)[:, :, :, l2g]
+                if rtol == 0.0:
+                    assert np.array_equal(got, want), f"level {i + 1} rank {r} {name}"
+                else:
+                    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * 1e-2, err_msg=f"level {i + 1} rank {r} {name}")
+            seen += l2g.size
+            ghosts += int(d[f"stats{i}"][1] - d[f"stats{i}"][0])
+        assert seen == g.n_blocks
+        cut_levels += ghosts > 0
+    return cut_levels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("levels", [2, 3])
+def test_two_ranks_nested_levels_cut_through_the_refinement(tmp_path, gpu, levels):
+    """Scope row N3: nested levels on 2 ranks, the cut passing through every level. The fine levels interpolate from
+    parent cells that live in parent GHOST blocks (f_k, rho, u and their saved old copies), Bouzidi cells sit on both sides.
+    Owned blocks of every level must equal the single-domain oracle bit for bit."""
+    nbg, steps = (8, 4, 4), 3
+    _launch("gpu_multilevel", tmp_path, nbg, steps, world=2, overlap=levels)
+    assert _check_multilevel(tmp_path, nbg, steps, levels, False, 2) == levels, "every level was meant to be cut"
+
+
+@pytest.mark.gpu
+def test_four_ranks_nested_levels_with_wall_model(tmp_path, gpu):
+    nbg, steps = (8, 4, 4), 2
+    _launch("gpu_multilevel", tmp_path, nbg, steps, world=4, overlap=2 | 8)
+    _check_multilevel(tmp_path, nbg, steps, 2, True, 4, rtol=1e-5)

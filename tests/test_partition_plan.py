@@ -82,3 +82,60 @@ def test_owned_blocks_keep_reference_order_and_ghosts_follow():
         assert (np.asarray(v.level.neighbor_table)[v.n_owned:] == 0).all()
         # every neighbour of an owned block is present locally (periodic box: 26 neighbours)
         assert (np.asarray(v.level.neighbor_table)[: v.n_owned] > 0).all()
+
+
+def test_interpolation_needs_match_a_per_link_walk():
+    """Parent-data ghosts (scope row N3): the vectorised list equals a plain per-link walk of the interface rule
+    (src/physics_interpolation.jl:29-62: source cell outside the fine level, 8 parent cells around (g - 0.5) / 2)."""
+    from open_ludwig_amd import cases
+    from open_ludwig_amd.blocks import build_lattice_arrays
+    nbg = (6, 4, 4)
+    grids, params = cases.tunnel_with_sphere(nbg, levels=2, wall_model=False, temporal=True)
+    cx, cy, cz = (np.asarray(a) for a in build_lattice_arrays()[:3])
+    bx = np.asarray(grids[0].active_block_coords)[:, 0]
+    owner1 = ((bx - 1) * 2 // nbg[0]).astype(np.int64)
+    total = 0
+    for rank in range(2):
+        views = []
+        for g in grids:
+            own = owner1 if g.level_id == 1 else partition.ancestor_owner(g.level_id, g.active_block_coords, grids[0].active_block_coords, owner1)
+            views.append(partition.build_local_level(g.level_id, g.active_block_coords, g.neighbor_table, own, rank, float(g.tau), temporal=True))
+        child, parent = views[1], views[0]
+        got = partition.interpolation_needs(child, parent, (params.domain_nx, params.domain_ny, params.domain_nz))
+        cl, pl = child.level, parent.level
+        pnb = pl.n_blocks
+        want_f, want_r = set(), set()
+        lim = (2 * params.domain_nx, 2 * params.domain_ny, 2 * params.domain_nz)
+        for b in range(child.n_owned):
+            if (cl.neighbor_table[b] != 0).all():
+                continue
+            org = [(int(m[b]) - 1) * 8 for m in (cl.map_x, cl.map_y, cl.map_z)]
+            for k in range(27):
+                c = (int(cx[k]), int(cy[k]), int(cz[k]))
+                for z in range(8):
+                    for y in range(8):
+                        for x in range(8):
+                            s = (x - c[0], y - c[1], z - c[2])
+                            o = [(-1 if v < 0 else (1 if v > 7 else 0)) for v in s]
+                            if o == [0, 0, 0] or cl.neighbor_table[b, (o[0] + 1) + 3 * (o[1] + 1) + 9 * (o[2] + 1)] != 0:
+                                continue
+                            g = [org[a] + s[a] + 1 for a in range(3)]
+                            if any(g[a] < 1 or g[a] > lim[a] for a in range(3)):
+                                continue
+                            lo = [max(int(np.floor((g[a] - 0.5) * 0.5)), 1) for a in range(3)]
+                            hi = [int(np.floor((g[a] - 0.5) * 0.5)) + 1 for a in range(3)]
+                            for n in range(8):
+                                pg = [hi[a] if (n >> a) & 1 else lo[a] for a in range(3)]
+                                pb = [(v - 1) // 8 for v in pg]
+                                if any(pb[a] < 0 or pb[a] >= pl.block_pointer.shape[a] for a in range(3)):
+                                    continue
+                                idx = int(pl.block_pointer[pb[0], pb[1], pb[2]])
+                                if idx > parent.n_owned:
+                                    cell = (pg[0] - 1) % 8 + 8 * ((pg[1] - 1) % 8) + 64 * ((pg[2] - 1) % 8)
+                                    want_f.add((k * pnb + idx - 1) * 512 + cell)
+                                    want_r.add((idx - 1) * 512 + cell)
+        assert set(got["f"].tolist()) == want_f
+        assert set(got["rho"].tolist()) == want_r
+        assert got["vel"].size == 3 * len(want_r)
+        total += len(want_f)
+    assert total > 0, "the cut was meant to pass through the refined region"
