@@ -52,6 +52,56 @@ class HipStepper:
             d.close()
 
 
+class DistributedStepper:
+    """grids spread over the ranks of the default torch.distributed group, one MI355X per rank (scope row N3): every
+    level is cut by the owner of its level-1 ancestor (partition.balanced_owner), halo + parent-data ghosts move after
+    every level step (partition.MultiLevelRunner). `field()` returns the GLOBAL array on every rank (owned blocks
+    all-gathered), so the diagnostics of run_case are computed exactly as in the single-device run."""
+
+    def __init__(self, host_grids, device: Optional[int] = None, owner_level1: Optional[np.ndarray] = None, stage_through_host: bool = False):
+        import torch.distributed as dist
+        from . import partition
+        self.dist, self.partition = dist, partition
+        self.host = host_grids
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device if device is not None else int(__import__("os").environ.get("LOCAL_RANK", "0"))
+        self.owner1 = owner_level1 if owner_level1 is not None else partition.balanced_owner(host_grids, self.world)
+        self.stage = stage_through_host
+        self.runner = None
+
+    def _start(self, params) -> None:
+        self.runner = self.partition.MultiLevelRunner(self.host, self.owner1, params, self.rank, self.world, self.device, self.stage)
+        for lv in self.runner.levels:
+            if lv is not None:
+                lv.init_equilibrium()          # src/main.jl:126-135 (ghost blocks included: same rest state everywhere)
+
+    def batch(self, t_start: int, n: int, u_curr, params) -> None:
+        if self.runner is None:
+            self._start(params)
+        self.runner.params = params
+        for t in range(t_start, t_start + n):
+            self.runner.step(t, u_curr)
+        self.runner.synchronize()
+
+    def field(self, level: int, name: str) -> np.ndarray:
+        lv, view = self.runner.levels[level], self.runner.views[level]
+        g = self.host[level]
+        mine = (view.local_to_global[: view.n_owned], lv.download(name)[:, :, :, : view.n_owned] if lv is not None else None)
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, mine)
+        out = np.zeros(getattr(g, name).shape, dtype=getattr(g, name).dtype, order="F")
+        for l2g, a in parts:
+            if a is not None and l2g.size:
+                out[:, :, :, l2g] = a
+        return out
+
+    def close(self):
+        if self.runner is not None:
+            for lv in self.runner.levels:
+                if lv is not None:
+                    lv.close()
+
+
 def flow_stats(rho: np.ndarray, obstacle: np.ndarray) -> float:
     """rho_min of compute_flow_stats (src/diagnostics.jl:56-94, CUDA branch): minimum over non-obstacle cells"""
     return float(rho[~obstacle].min())

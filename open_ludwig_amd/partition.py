@@ -479,6 +479,45 @@ def ancestor_owner(level_id: int, coords, level1_coords, level1_owner: np.ndarra
     return np.array([lut[(int(a) + 1, int(b) + 1, int(d) + 1)] for a, b, d in c], dtype=np.int64)
 
 
+def balanced_owner(grids: Sequence[BlockLevel], world: int) -> np.ndarray:
+    """Owner of every level-1 block for nested levels: recursive coordinate bisection with planar cuts, weighted by the
+    work below each level-1 block (its own step + 2^(l-1) sub-steps of every level-l descendant block per coarse step)."""
+    c1 = np.asarray(grids[0].active_block_coords, dtype=np.int64)
+    lut = {tuple(c): i for i, c in enumerate(c1)}
+    w = np.ones(len(c1), dtype=np.float64)
+    for g in grids[1:]:
+        anc = ((np.asarray(g.active_block_coords, dtype=np.int64).reshape(-1, 3) - 1) >> (g.level_id - 1)) + 1
+        np.add.at(w, [lut[tuple(a)] for a in anc], float(2 ** (g.level_id - 1)))
+    owner = np.zeros(len(c1), dtype=np.int64)
+
+    def split(ids: np.ndarray, r0: int, n: int) -> None:
+        if n == 1 or ids.size == 0:
+            owner[ids] = r0
+            return
+        n_lo = n // 2
+        ext = c1[ids].max(axis=0) - c1[ids].min(axis=0)
+        best = None
+        for axis in np.argsort(-ext, kind="stable"):
+            planes = np.unique(c1[ids, axis])
+            if planes.size < 2:
+                continue
+            below = np.array([w[ids][c1[ids, axis] <= p].sum() for p in planes[:-1]])
+            target = w[ids].sum() * n_lo / n
+            j = int(np.argmin(np.abs(below - target)))
+            best = (axis, planes[j])
+            break
+        if best is None:                       # a single block column left: nothing to cut
+            owner[ids] = r0
+            return
+        lo = ids[c1[ids, best[0]] <= best[1]]
+        hi = ids[c1[ids, best[0]] > best[1]]
+        split(lo, r0, n_lo)
+        split(hi, r0 + n_lo, n - n_lo)
+
+    split(np.arange(len(c1)), 0, world)
+    return owner
+
+
 def interpolation_needs(child: LocalView, parent: LocalView, domain_cells: Tuple[int, int, int]) -> Dict[str, np.ndarray]:
     """Parent-level ghost elements the child's coarse->fine interface reads (src/physics_interpolation.jl:29-62):
     for every link (owned child cell, k) whose source block is missing and whose source cell lies inside the global box,

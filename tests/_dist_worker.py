@@ -65,6 +65,30 @@ def main():
         runner.synchronize()
         res = {n: runner.level.download(n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
         res["nbc"] = np.array([runner.level.n_boundary_cells, int(runner.ex.plan.has("f_post"))])
+    elif mode == "gpu_case":
+        # the ball1m case (YAML + STL -> 3 nested levels, wall model, Bouzidi sphere) through run_case on `world` ranks
+        import json
+        from open_ludwig_amd import case, preprocess as pp
+        G = os.path.join(ROOT, "tests", "golden")
+        cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"),
+                                         {"basic": {"surface_resolution": 25, "flow": {"velocity": 4.0}, "simulation": {"steps": 6000, "output_freq": 1000}}})
+        cfg.diag_freq = 20
+        setup = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
+        holder = {}
+
+        def factory(grids):
+            holder["st"] = case.DistributedStepper(grids, device=0, stage_through_host=True)
+            return holder["st"]
+
+        rows, rep, _ = case.run_case(cfg, factory, steps=steps, setup=setup)
+        st = holder["st"]
+        stats = [[v.n_owned, v.level.n_blocks, st.runner.ex[i].plan.bytes_per_step()] for i, v in enumerate(st.runner.views)]
+        if rank == 0:
+            json.dump({"rows": [[r.step, r.u_lat, r.rho_min, r.cd, r.cl] for r in rows]}, open(os.path.join(outdir, "rows.json"), "w"))
+        json.dump(stats, open(os.path.join(outdir, f"stats{rank}.json"), "w"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     elif mode == "gpu_multilevel":
         # nested levels (interface interpolation from parent-data ghosts, temporal blend, Bouzidi sphere), split along x
         levels, wall = overlap & 7, bool(overlap & 8)

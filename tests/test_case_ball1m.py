@@ -115,3 +115,27 @@ def test_cube1m_hip_equals_oracle(gpu):
     assert [r.step for r in hip] == [16, 32, 48] == [r.step for r in ora]
     for a, b in zip(hip, ora):
         assert a.rho_min == b.rho_min and a.cd == b.cd and a.cl == b.cl, (a, b)      # bounce-back, no wall model: exact
+
+
+@pytest.mark.gpu
+def test_ball1m_on_two_ranks_equals_single_device(gpu, ball_setup, tmp_path):
+    """Scope row N3 end to end: the same case through run_case on 2 ranks (cut through all three levels, wall model on,
+    Bouzidi sphere split between the ranks) gives the Cd / Cl / rho_min rows of the single-device run, digit for digit."""
+    import copy
+    import json
+    import test_partition_dist as tpd
+    cfg, setup = ball_setup
+    cfg = copy.copy(cfg)
+    cfg.diag_freq = 20
+    steps = 60
+    single, _, _ = case.run_case(cfg, case.HipStepper, steps=steps, setup=setup)
+    tpd._launch("gpu_case", tmp_path, (0, 0, 0), steps, world=2)
+    rows = json.load(open(os.path.join(tmp_path, "rows.json")))["rows"]
+    assert len(rows) == len(single) == 3
+    for got, want in zip(rows, single):
+        assert got[0] == want.step
+        assert got[1:] == [want.u_lat, want.rho_min, want.cd, want.cl], (got, want)
+    stats = [json.load(open(os.path.join(tmp_path, f"stats{r}.json"))) for r in range(2)]
+    for lvl in range(3):
+        assert sum(s[lvl][0] for s in stats) == setup[0][lvl].n_blocks
+        assert all(s[lvl][1] > s[lvl][0] for s in stats), "every level was meant to be cut"
