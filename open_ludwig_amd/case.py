@@ -10,6 +10,7 @@ and, in tests only, the CPU oracle.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional
 
@@ -108,8 +109,14 @@ def flow_stats(rho: np.ndarray, obstacle: np.ndarray) -> float:
 
 
 def run_case(cfg: CaseConfig, stepper_factory: Callable = HipStepper, steps: Optional[int] = None, stl_path: Optional[str] = None,
-             log: Optional[Callable[[str], None]] = None, setup=None):
-    """solve_main (src/main.jl:54-249) minus VTK/CSV output. Returns (rows, setup_report, params)."""
+             log: Optional[Callable[[str], None]] = None, setup=None, out_dir: Optional[str] = None, write_files: bool = True):
+    """solve_main (src/main.jl:54-249). Returns (rows, setup_report, params).
+
+    out_dir: when given, the reference's result files are written there (row N4): convergence.csv and forces.csv at every
+    diagnostics step, flow_%06d.vtu (+ surface_%06d.vtu) every `output_freq` steps. Unlike the reference (main.jl:79) an
+    existing directory is NOT emptied first. write_files=False on all ranks but one of a distributed run."""
+    import time as _time
+    from . import output as out_mod
     grids, mesh, params, report = setup if setup is not None else setup_multilevel_domain(cfg, stl_path)
     sp = solver_params(cfg, params)
     st = stepper_factory(grids)
@@ -117,6 +124,16 @@ def run_case(cfg: CaseConfig, stepper_factory: Callable = HipStepper, steps: Opt
     rows: List[DiagRow] = []
     batch = cfg.async_depth
     t = 1
+    writing = out_dir is not None and write_files
+    if writing:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "convergence.csv"), "w") as io:
+            io.write(out_mod.CONVERGENCE_CSV_HEADER + "\n")
+        if cfg.forces_enabled:
+            out_mod.write_force_csv_header(os.path.join(out_dir, "forces.csv"))
+    t0 = last_diag = _time.time()
+    total_cells = sum(g.n_blocks * 512 for g in grids)
+    fr = None
     try:
         while t <= total_steps:
             batch_end = min(t + batch - 1, total_steps)
@@ -135,8 +152,41 @@ def run_case(cfg: CaseConfig, stepper_factory: Callable = HipStepper, steps: Opt
                         fr = forces_mod.compute_aerodynamics(mesh, grids[fin], rho_f, st.field(fin, "vel"), params, cfg.symmetric_analysis)
                         cd, cl, cs, cmy = fr.Cd, fr.Cl, fr.Cs, fr.Cmy
                     rows.append(DiagRow(diag_step, float(u_curr), rho_min, cd, cl, cs, cmy))
+                    now = _time.time()
+                    mlups = (total_cells * cfg.diag_freq) / (max(now - last_diag, 1e-9) * 1e6)     # src/main.jl:189
+                    last_diag = now
+                    if writing:
+                        time_phys = float(diag_step) * params.time_scale
+                        if cfg.forces_enabled:
+                            out_mod.append_force_csv(os.path.join(out_dir, "forces.csv"), diag_step, time_phys, fr, u_curr)
+                        with open(os.path.join(out_dir, "convergence.csv"), "a") as io:
+                            io.write(out_mod.convergence_csv_row(diag_step, now - t0, time_phys, u_curr, rho_min, mlups,
+                                                                 cd if cfg.forces_enabled else None, cl if cfg.forces_enabled else None) + "\n")
                     if log:
                         log(f"{diag_step:8d} | {float(u_curr):.4f} | {rho_min:.4f} | {cd:8.4f} | {cl:8.4f}")
+            if out_dir is not None and batch_end % cfg.output_freq < actual:                      # src/main.jl:213-231
+                out_step = (batch_end // cfg.output_freq) * cfg.output_freq
+                if t <= out_step <= batch_end:
+                    fetched = {}
+
+                    def fields(lvl, name):
+                        if name == "obstacle":
+                            return grids[lvl].obstacle
+                        if (lvl, name) not in fetched:
+                            fetched[(lvl, name)] = st.field(lvl, name)          # collective in a distributed run
+                        return fetched[(lvl, name)]
+
+                    mesh_arrays_needed = out_mod.select_export_blocks([g.active_block_coords for g in grids])
+                    vel_name = "vel_temp" if out_step % 2 == 0 else "vel"
+                    for lvl in sorted({l for l, _ in mesh_arrays_needed}):
+                        fields(lvl, "rho"); fields(lvl, vel_name)
+                    if cfg.forces_enabled and (fr is None or out_step != (out_step // cfg.diag_freq) * cfg.diag_freq):
+                        fin = len(grids) - 1
+                        fr = forces_mod.compute_aerodynamics(mesh, grids[fin], fields(fin, "rho"), st.field(fin, "vel"), params, cfg.symmetric_analysis)
+                    if writing:
+                        out_mod.export_merged_mesh(out_step, grids, fields, out_dir, cfg.output_fields)
+                        if cfg.forces_enabled:
+                            out_mod.save_surface_vtk(os.path.join(out_dir, "surface_%06d" % out_step), mesh, *fr.maps)
             t = batch_end + 1
     finally:
         if hasattr(st, "close"):

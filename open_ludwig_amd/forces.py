@@ -13,6 +13,7 @@ pairwise sums (deterministic), which is one of the orders the reference could ha
 from __future__ import annotations
 
 from dataclasses import dataclass
+from typing import Optional
 from typing import Tuple
 
 import numpy as np
@@ -30,6 +31,7 @@ class ForceResult:
     Fx_viscous: float; Fy_viscous: float; Fz_viscous: float
     Cd: float; Cl: float; Cs: float; Cmx: float; Cmy: float; Cmz: float
     coverage: int
+    maps: Optional[tuple] = None      # (p, tau_x, tau_y, tau_z) per triangle [Pa], kept for the surface VTU / loads CSV
 
 
 def map_surface_stresses(mesh, rho, vel, obstacle, block_pointer, dx, tau, params, search_radius: int = 5):
@@ -150,4 +152,6 @@ def compute_aerodynamics(mesh, level_host, rho, vel, params, symmetric: bool = F
     (not vel_temp), as the reference reads it (src/forces/surface.jl:412, Appendix A.13)."""
     p, tx, ty, tz = map_surface_stresses(mesh, rho, vel, level_host.obstacle, level_host.block_pointer, level_host.dx, level_host.tau,
                                          params, search_radius)
-    return integrate_surface_forces(mesh, p, tx, ty, tz, params, symmetric)
+    fr = integrate_surface_forces(mesh, p, tx, ty, tz, params, symmetric)
+    fr.maps = (p, tx, ty, tz)
+    return fr

@@ -93,6 +93,7 @@ class CaseConfig:
     diag_freq: int = 500
     async_depth: int = 8
     case_dir: str = ""
+    output_fields: Tuple[str, ...] = ("Density", "Velocity", "VelocityMagnitude", "Obstacle", "Level")   # io_vtk.jl:116-120
 
     @property
     def reference_area_config(self) -> float:
@@ -151,6 +152,10 @@ def load_case_configuration(config_path: str, overrides: Optional[dict] = None) 
         moment_center=tuple(float(v) for v in g("advanced", "forces", "moment_center", default=[0.25, 0.0, 0.0])),
         diag_freq=int(g("advanced", "diagnostics", "freq", default=500)), async_depth=int(g("advanced", "gpu", "async_depth", default=8)),
         case_dir=os.path.dirname(os.path.abspath(config_path)),
+        # vorticity / bouzidi are read by the reference's loader (config_loader.jl:145,148) but never written by io_vtk.jl
+        output_fields=tuple(name for key, name in (("density", "Density"), ("velocity", "Velocity"), ("velocity_magnitude", "VelocityMagnitude"),
+                                                   ("obstacle", "Obstacle"), ("level", "Level"))
+                            if bool(g("basic", "simulation", "output_fields", key, default=True))),
     )
 
 

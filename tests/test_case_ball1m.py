@@ -139,3 +139,32 @@ def test_ball1m_on_two_ranks_equals_single_device(gpu, ball_setup, tmp_path):
     for lvl in range(3):
         assert sum(s[lvl][0] for s in stats) == setup[0][lvl].n_blocks
         assert all(s[lvl][1] > s[lvl][0] for s in stats), "every level was meant to be cut"
+
+
+@pytest.mark.gpu
+def test_ball1m_result_files(gpu, ball_setup, tmp_path):
+    """Scope row N4 through run_case: convergence.csv / forces.csv rows at the diagnostics steps, flow + surface VTU at the
+    output steps; the flow file holds the leaf blocks of all three levels and the density the diagnostics saw."""
+    import copy
+    from test_output_files import read_vtu
+    from open_ludwig_amd import output
+    cfg, setup = ball_setup
+    cfg = copy.copy(cfg)
+    cfg.diag_freq, cfg.output_freq = 16, 32
+    rows, _, params = case.run_case(cfg, case.HipStepper, steps=48, setup=setup, out_dir=str(tmp_path))
+    assert sorted(os.listdir(tmp_path)) == ["convergence.csv", "flow_000032.vtu", "forces.csv", "surface_000032.vtu"]
+    conv = open(tmp_path / "convergence.csv").read().splitlines()
+    frc = open(tmp_path / "forces.csv").read().splitlines()
+    assert conv[0] == output.CONVERGENCE_CSV_HEADER and frc[0] == output.FORCE_CSV_HEADER and len(conv) == len(frc) == 4
+    for r, c, f in zip(rows, conv[1:], frc[1:]):
+        cc, ff = c.split(","), f.split(",")
+        assert int(cc[0]) == int(ff[0]) == r.step and cc[6] == "%.4f" % r.cd and cc[7] == "%.4f" % r.cl
+        assert ff[11] == "%.6f" % r.cd and float(ff[1]) == pytest.approx(r.step * params.time_scale, rel=1e-6)
+        assert np.float32(cc[4]) == np.float32(r.rho_min)
+    grids = setup[0]
+    d = read_vtu(str(tmp_path / "flow_000032.vtu"))
+    sel = output.select_export_blocks([g.active_block_coords for g in grids])
+    assert d["n_cells"] == 512 * len(sel) and set(np.unique(d["Level"])) == {1, 2, 3}
+    assert int((d["Obstacle"] == 1).sum()) == sum(int(grids[l].obstacle[:, :, :, b].sum()) for l, b in sel)
+    s = read_vtu(str(tmp_path / "surface_000032.vtu"))
+    assert s["n_cells"] == 20480 and s["MappingQuality"].mean() > 0.9 and np.isfinite(s["Pressure_Pa"]).all()
