@@ -47,7 +47,7 @@ class LevelHost(C.Structure):
         ("enable_temporal_interpolation", C.c_int32), ("n_boundary_cells", C.c_int32),
         ("bouzidi_q_map", C.c_void_p), ("bouzidi_cell_block", C.c_void_p),
         ("bouzidi_cell_x", C.c_void_p), ("bouzidi_cell_y", C.c_void_p), ("bouzidi_cell_z", C.c_void_p),
-        ("comm_boundary", C.c_void_p),
+        ("comm_boundary", C.c_void_p), ("store_post_collision_everywhere", C.c_int32),
     ]
 
 

@@ -220,6 +220,7 @@ class DeviceLevel:
             h.bouzidi_cell_z = ptr(host.bouzidi_cell_z, np.int8)
         if host.comm_boundary is not None:
             h.comm_boundary = ptr(host.comm_boundary, np.uint8)
+        h.store_post_collision_everywhere = 1 if getattr(host, "force_post_collision", False) else 0
         handle = C.c_void_p()
         _lib.check(lib.ludwig_level_create(C.byref(h), device, C.byref(handle)))
         self._h = handle

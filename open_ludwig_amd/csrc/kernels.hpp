@@ -369,6 +369,10 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
         if constexpr (cz == 1) jz += val; else if constexpr (cz == -1) jz -= val;
     });
 
+    // the reference stores f_post_collision for every cell of a Bouzidi level (src/physics_kernels.jl:350-352); its only
+    // reader is the Bouzidi kernel, at boundary cells and their link neighbours, so blocks that neither hold nor touch a
+    // boundary cell skip the dead store (wave-uniform flag; 108 of 357 B per cell update)
+    const bool store_post = (flags & FLAG_STORE_POST) != 0;
     // ---- obstacle cell: full-way bounce-back of the pulled set, reference :154-166 ----
     bool is_obs = false;
     if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own_bytes >> 2] != 0;
@@ -381,7 +385,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
             constexpr int k = decltype(kc)::value;
             const float f_coll = fs[OPP(k)];
             st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
-            if constexpr (POST) st_f32(p.f_post + p.sk * k, own_bytes, f_coll);
+            if constexpr (POST) { if (store_post) st_f32(p.f_post + p.sk * k, own_bytes, f_coll); }
         });
         return;
     }
@@ -503,7 +507,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
                                                      (cz_f - uz + 3.0f * cu * cz_f) * Fz);
             f_coll = f_coll + one_m_half_omega * force_term;
         }
-        if constexpr (POST) st_f32(p.f_post + p.sk * k, own_bytes, f_coll);
+        if constexpr (POST) { if (store_post) st_f32(p.f_post + p.sk * k, own_bytes, f_coll); }
         st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
     });
 }
@@ -765,16 +769,23 @@ struct CornerRef {
     int64_t c;       // cell offset in the parent arrays, -1 = invalid corner
 };
 
-__global__ __launch_bounds__(128) void k_interface_links(const SCParams p, const int4 *__restrict__ sources, int n_sources,
+constexpr int IFACE_SOURCES_PER_WG = 32;     // 8 lanes per source cell, 256 threads
+
+__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const int4 *__restrict__ sources, int n_sources,
                                                           const int2 *__restrict__ links)
 {
-    // one thread per SOURCE cell (a fine-grid cell just outside this level's blocks): the trilinear rho / u of
-    // reference src/physics_interpolation.jl:110-124 are the same for every population pulled from it, so they are
-    // computed once; then one f interpolation per link. Expression by expression identical to interpolate_with_rescaling.
-    const int i = blockIdx.x * 128 + threadIdx.x;
-    if (i >= n_sources) return;
-    const int4 s = sources[i];                       // fine_gx, fine_gy, fine_gz, first link
-    const int last = sources[i + 1].w;               // sentinel entry closes the last segment
+    // 8 lanes per SOURCE cell (a fine-grid cell just outside this level's blocks). Lane n fetches corner n of the
+    // trilinear stencil (rho / u of reference src/physics_interpolation.jl:110-124 are the same for every population
+    // pulled from the source, so they are fetched once); the 8 corners meet in LDS; then the lanes share the source's
+    // links, one f interpolation per link. Every lane evaluates the full expressions of interpolate_with_rescaling on all
+    // 8 corners in the reference's order: bit-identical to the inline call, only the latency chain is 8x shorter.
+    __shared__ float sh_v[IFACE_SOURCES_PER_WG][8][4];
+    __shared__ int sh_c[IFACE_SOURCES_PER_WG][8];
+    const int g = threadIdx.x >> 3, n = threadIdx.x & 7;
+    const int i = blockIdx.x * IFACE_SOURCES_PER_WG + g;
+    const bool live = i < n_sources;
+    const int4 s = live ? sources[i] : make_int4(1, 1, 1, 0);      // fine_gx, fine_gy, fine_gz, first link
+    const int last = live ? sources[i + 1].w : 0;                    // sentinel entry closes the last segment
     const float px_cont = ((float)s.x - 0.5f) * 0.5f, py_cont = ((float)s.y - 0.5f) * 0.5f, pz_cont = ((float)s.z - 0.5f) * 0.5f;
     int px0 = (int)floorf(px_cont), py0 = (int)floorf(py_cont), pz0 = (int)floorf(pz_cont);
     const int px1 = px0 + 1, py1 = py0 + 1, pz1 = pz0 + 1;
@@ -782,57 +793,64 @@ __global__ __launch_bounds__(128) void k_interface_links(const SCParams p, const
     px0 = max(1, px0); py0 = max(1, py0); pz0 = max(1, pz0);
     const bool blend = p.use_temporal == 1 && p.temporal_weight < 0.99f;
     const float tw = p.temporal_weight;
-    int64_t cc[8];
-    float rho_c[8], ux_c[8], uy_c[8], uz_c[8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {                    // corner order 000,100,010,110,001,101,011,111
+    {                                                // corner order 000,100,010,110,001,101,011,111
         const int pgx = (n & 1) ? px1 : px0, pgy = (n & 2) ? py1 : py0, pgz = (n & 4) ? pz1 : pz0;
         const int pbx = (pgx - 1) / BS + 1, pby = (pgy - 1) / BS + 1, pbz = (pgz - 1) / BS + 1;
-        cc[n] = -1;
-        rho_c[n] = 1.0f; ux_c[n] = 0.0f; uy_c[n] = 0.0f; uz_c[n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
-        if (pbx >= 1 && pbx <= p.pdim_x && pby >= 1 && pby <= p.pdim_y && pbz >= 1 && pbz <= p.pdim_z) {
+        int c = -1;
+        float r = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;           // (w_k, 1, 0, 0, 0, false) default
+        if (live && pbx >= 1 && pbx <= p.pdim_x && pby >= 1 && pby <= p.pdim_y && pbz >= 1 && pbz <= p.pdim_z) {
             const int32_t pb = p.pptr[(int64_t)(pbx - 1) + (int64_t)p.pdim_x * ((int64_t)(pby - 1) + (int64_t)p.pdim_y * (pbz - 1))];
             if (pb > 0) {
-                const int64_t c = (int64_t)((pgx - 1) % BS) + 8 * ((pgy - 1) % BS) + 64 * ((pgz - 1) % BS) + 512 * (int64_t)(pb - 1);
-                cc[n] = c;
+                c = ((pgx - 1) % BS) + 8 * ((pgy - 1) % BS) + 64 * ((pgz - 1) % BS) + 512 * (pb - 1);
                 const float rn = p.prho_new[c], un = p.pvel_new[c], vn = p.pvel_new[c + p.psk], wn = p.pvel_new[c + 2 * p.psk];
                 if (blend) {
-                    rho_c[n] = p.prho_old[c] * (1.0f - tw) + rn * tw;
-                    ux_c[n] = p.pvel_old[c] * (1.0f - tw) + un * tw;
-                    uy_c[n] = p.pvel_old[c + p.psk] * (1.0f - tw) + vn * tw;
-                    uz_c[n] = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + wn * tw;
+                    r = p.prho_old[c] * (1.0f - tw) + rn * tw;
+                    ux = p.pvel_old[c] * (1.0f - tw) + un * tw;
+                    uy = p.pvel_old[c + p.psk] * (1.0f - tw) + vn * tw;
+                    uz = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + wn * tw;
                 } else {
-                    rho_c[n] = rn; ux_c[n] = un; uy_c[n] = vn; uz_c[n] = wn;
+                    r = rn; ux = un; uy = vn; uz = wn;
                 }
             }
         }
+        sh_c[g][n] = c;
+        sh_v[g][n][0] = r; sh_v[g][n][1] = ux; sh_v[g][n][2] = uy; sh_v[g][n][3] = uz;
+    }
+    __syncthreads();
+    if (!live) return;
+    int cc[8];
+    float rho_c[8], ux_c[8], uy_c[8], uz_c[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        cc[m] = sh_c[g][m];
+        rho_c[m] = sh_v[g][m][0]; ux_c[m] = sh_v[g][m][1]; uy_c[m] = sh_v[g][m][2]; uz_c[m] = sh_v[g][m][3];
     }
     // invalid corners take corner 000's tuple (which may itself be the default), reference :100-107
 #pragma unroll
-    for (int n = 1; n < 8; ++n)
-        if (cc[n] < 0) { rho_c[n] = rho_c[0]; ux_c[n] = ux_c[0]; uy_c[n] = uy_c[0]; uz_c[n] = uz_c[0]; }
+    for (int m = 1; m < 8; ++m)
+        if (cc[m] < 0) { rho_c[m] = rho_c[0]; ux_c[m] = ux_c[0]; uy_c[m] = uy_c[0]; uz_c[m] = uz_c[0]; }
     const float rho_int = trilin(rho_c[0], rho_c[1], rho_c[2], rho_c[3], rho_c[4], rho_c[5], rho_c[6], rho_c[7], wx, wy, wz);
     const float ux_int = trilin(ux_c[0], ux_c[1], ux_c[2], ux_c[3], ux_c[4], ux_c[5], ux_c[6], ux_c[7], wx, wy, wz);
     const float uy_int = trilin(uy_c[0], uy_c[1], uy_c[2], uy_c[3], uy_c[4], uy_c[5], uy_c[6], uy_c[7], wx, wy, wz);
     const float uz_int = trilin(uz_c[0], uz_c[1], uz_c[2], uz_c[3], uz_c[4], uz_c[5], uz_c[6], uz_c[7], wx, wy, wz);
     const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
     const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
-    for (int j = s.w; j < last; ++j) {
+    for (int j = s.w + n; j < last; j += 8) {
         const int2 l = links[j];
         const int cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5;
         const float w_k = weight_rt(k);
         float fc[8];
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            fc[n] = w_k;
-            if (cc[n] >= 0) {
-                const float fn = p.pf_new[cc[n] + p.psk * k];
-                fc[n] = blend ? p.pf_old[cc[n] + p.psk * k] * (1.0f - tw) + fn * tw : fn;
+        for (int m = 0; m < 8; ++m) {
+            fc[m] = w_k;
+            if (cc[m] >= 0) {
+                const float fn = p.pf_new[(int64_t)cc[m] + p.psk * k];
+                fc[m] = blend ? p.pf_old[(int64_t)cc[m] + p.psk * k] * (1.0f - tw) + fn * tw : fn;
             }
         }
 #pragma unroll
-        for (int n = 1; n < 8; ++n)
-            if (cc[n] < 0) fc[n] = fc[0];
+        for (int m = 1; m < 8; ++m)
+            if (cc[m] < 0) fc[m] = fc[0];
         const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], wx, wy, wz);
         const float feq_int = calculate_equilibrium(rho_int, ux_int, uy_int, uz_int, w_k, (float)(k % 3 - 1), (float)((k / 3) % 3 - 1), (float)(k / 9 - 1));
         const float f_neq = f_int - feq_int;

@@ -36,5 +36,6 @@ constexpr int FLAG_ALL_NEIGHBOURS = 1;   // all 26 neighbour blocks present -> n
 constexpr int FLAG_HAS_OBSTACLE = 2;
 constexpr int FLAG_HAS_SPONGE = 4;
 constexpr int FLAG_HAS_NEAR_WALL = 8;    // some cell with 0 < wall_dist < 10
+constexpr int FLAG_STORE_POST = 16;      // f_post_collision has a reader here: the block holds a Bouzidi cell or touches one
 
 }  // namespace lw

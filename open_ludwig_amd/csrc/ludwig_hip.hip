@@ -58,6 +58,10 @@ struct LudwigLevel {
     float *sponge = nullptr, *wall_dist = nullptr;
     int32_t *meta = nullptr, *block_pointer = nullptr;
     bool has_temporal = false, has_post = false, bouzidi_enabled = false;
+    // copy_to_old! without the copies: a pull step never writes its input buffers, so after ludwig_save_old(t_sub) the saved
+    // f / vel ARE f[in] / vel[in] until something else writes that buffer. old_alias = that buffer index, or -1 when the
+    // saved state lives in f_old / vel_old (materialize_old() copies it there before any such write). rho is copied.
+    int old_alias = -1;
     int n_bc = 0;
     _Float16 *q_map = nullptr;
     int32_t *cell_block = nullptr;
@@ -104,9 +108,35 @@ struct FieldDesc {
     size_t bytes;
 };
 
+int materialize_old(LudwigLevel *L)
+{
+    if (L->old_alias < 0) return LUDWIG_OK;
+    const size_t c = (size_t)L->sk;
+    const int a = L->old_alias;
+    L->old_alias = -1;
+    LW_HIP(hipSetDevice(L->device));
+    LW_HIP(hipMemcpyAsync(L->f_old, L->f[a], c * Q * 4, hipMemcpyDeviceToDevice, L->stream));
+    LW_HIP(hipMemcpyAsync(L->vel_old, L->vel[a], c * 3 * 4, hipMemcpyDeviceToDevice, L->stream));
+    return LUDWIG_OK;
+}
+
+// call before anything but a stream-collide step writes `field` (upload, halo unpack, a raw pointer handed out)
+int before_external_write(LudwigLevel *L, int field)
+{
+    if (L->old_alias < 0) return LUDWIG_OK;
+    const int a = L->old_alias;
+    const bool hits = field == LUDWIG_F_OLD || field == LUDWIG_VEL_OLD || (field == LUDWIG_F && a == 0) || (field == LUDWIG_F_TEMP && a == 1) ||
+                      (field == LUDWIG_VEL && a == 0) || (field == LUDWIG_VEL_TEMP && a == 1);
+    return hits ? materialize_old(L) : LUDWIG_OK;
+}
+
 FieldDesc field_desc(const LudwigLevel *L, int field)
 {
     const size_t c = (size_t)L->sk;
+    if (L->old_alias >= 0) {          // readers of the saved state follow the alias
+        if (field == LUDWIG_F_OLD) return {L->f[L->old_alias], L->has_temporal ? c * Q * 4 : 0};
+        if (field == LUDWIG_VEL_OLD) return {L->vel[L->old_alias], L->has_temporal ? c * 3 * 4 : 0};
+    }
     switch (field) {
     case LUDWIG_F: return {L->f[0], c * Q * 4};
     case LUDWIG_F_TEMP: return {L->f[1], c * Q * 4};
@@ -353,6 +383,10 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     if (parent && parent->device != L->device) return fail(LUDWIG_ERR_INVALID, "parent level lives on another device");
     LW_HIP(hipSetDevice(L->device));
     const int in = (t_sub % 2 == 0) ? 0 : 1, out = 1 - in;   // reference src/solver_control.jl:35-41
+    if (L->old_alias == out) {                               // about to overwrite the buffer that holds the saved state
+        const int r = materialize_old(L);
+        if (r) return r;
+    }
     SCParams p{};
     p.f_in = L->f[in];
     p.f_out = L->f[out];
@@ -374,9 +408,9 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.prho_new = parent->rho;
         // without temporal storage the reference passes 1-element dummies that are never read
         // (use_temporal_interp is then false at every call site that matters); alias "new" to stay in bounds
-        p.pf_old = parent->has_temporal ? parent->f_old : parent->f[pout];
+        p.pf_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->f[parent->old_alias] : parent->f_old) : parent->f[pout];
         p.prho_old = parent->has_temporal ? parent->rho_old : parent->rho;
-        p.pvel_old = parent->has_temporal ? parent->vel_old : parent->vel[pout];
+        p.pvel_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->vel[parent->old_alias] : parent->vel_old) : parent->vel[pout];
         p.pptr = parent->block_pointer;
         p.pdim_x = parent->gdx; p.pdim_y = parent->gdy; p.pdim_z = parent->gdz;
         p.psk = parent->sk;
@@ -408,8 +442,8 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.f_iface = L->f_iface;
         p.n_iface_blocks = L->n_iface_blocks;
         if (L->n_links[part] > 0) {
-            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_sources[part] + 127) / 128)), dim3(128), 0, L->stream, p, L->sources[part],
-                               L->n_sources[part], L->links[part]);
+            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_sources[part] + IFACE_SOURCES_PER_WG - 1) / IFACE_SOURCES_PER_WG)), dim3(256), 0,
+                               L->stream, p, L->sources[part], L->n_sources[part], L->links[part]);
             LW_HIP(hipGetLastError());
         }
     }
@@ -417,9 +451,10 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         if (L->n_items[part][c] == 0) continue;
         p.items = L->items[part][c];
         const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
-#define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, L->stream, p)
-#define LW_LAUNCH_X(P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, L->stream, p); \
-            else hipLaunchKernelGGL((k_stream_collide_xrun<4, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, L->stream, p); } while (0)
+        const hipStream_t cs = L->stream;
+#define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, cs, p)
+#define LW_LAUNCH_X(P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, cs, p); \
+            else hipLaunchKernelGGL((k_stream_collide_xrun<4, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, cs, p); } while (0)
         if (c == 0) {
             if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
             else      { if (wall) LW_LAUNCH(false, false, true); else LW_LAUNCH(false, false, false); }
@@ -616,6 +651,18 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
             LW_HIP(hipMemcpy(L->cell_y, cy.data(), cy.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_z, cz.data(), cz.size(), hipMemcpyHostToDevice));
         }
+        if (L->has_post) {
+            // where f_post_collision has a reader: blocks with a Bouzidi cell and their 26 neighbours (a link q < 1/2 reads
+            // the cell one step behind, possibly across a block face). No cell list on this rank (forced store, multi-GPU:
+            // the readers are a peer's cells), store_post_collision_everywhere or LUDWIG_FULL_POST_COLLISION set: every block, as the reference.
+            const bool everywhere = L->n_bc == 0 || h->store_post_collision_everywhere != 0 || getenv("LUDWIG_FULL_POST_COLLISION") != nullptr;
+            for (int b = 0; b < L->n_blocks && everywhere; ++b) L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
+            for (int i = 0; i < L->n_bc && !everywhere; ++i) {
+                const int32_t *row = &L->h_meta[(size_t)(h->bouzidi_cell_block[i] - 1) * NBR_STRIDE];
+                for (int d = 0; d < 27; ++d)
+                    if (row[d] >= 0) L->h_meta[(size_t)row[d] * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
+            }
+        }
         LW_HIP(hipStreamSynchronize(L->stream));
         int r2 = upload_meta(L);
         if (r2) return r2;
@@ -666,7 +713,11 @@ int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t byte
     if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
     if (bytes != d.bytes) return fail(LUDWIG_ERR_INVALID, "field %d: got %zu bytes, expected %zu", field, bytes, d.bytes);
     LW_HIP(hipSetDevice(L->device));
-    LW_HIP(hipMemcpyAsync(d.ptr, host, bytes, hipMemcpyHostToDevice, L->stream));
+    {
+        const int r = before_external_write(L, field);
+        if (r) return r;
+    }
+    LW_HIP(hipMemcpyAsync(field_desc(L, field).ptr, host, bytes, hipMemcpyHostToDevice, L->stream));
     LW_HIP(hipStreamSynchronize(L->stream));
     if (field == LUDWIG_OBSTACLE || field == LUDWIG_SPONGE || field == LUDWIG_WALL_DIST) {
         scan_flags(L, field, host);
@@ -690,6 +741,10 @@ int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t by
 int ludwig_level_field_ptr(const LudwigLevel *L, int field, void **device_ptr, size_t *bytes)
 {
     if (!L || !device_ptr) return fail(LUDWIG_ERR_INVALID, "null argument");
+    {   // the caller may write through the pointer: give the saved state its own storage first
+        const int r = before_external_write(const_cast<LudwigLevel *>(L), field);
+        if (r) return r;
+    }
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
     *device_ptr = d.ptr;
@@ -706,6 +761,7 @@ int ludwig_init_equilibrium(LudwigLevel *L)
     hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[0], L->sk);
     hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[1], L->sk);
     if (L->has_temporal) {
+        L->old_alias = -1;
         hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f_old, L->sk);
         int r = fill(L, L->rho_old, L->sk, 1.0f);
         if (r) return r;
@@ -738,9 +794,9 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
     LW_HIP(hipSetDevice(L->device));
     const int in = (t_sub % 2 == 0) ? 0 : 1;
     const size_t c = (size_t)L->sk;
-    LW_HIP(hipMemcpyAsync(L->f_old, L->f[in], c * Q * 4, hipMemcpyDeviceToDevice, L->stream));
+    // f and vel: no copy - the step that follows reads f[in] / vel[in] and never writes them (see old_alias)
+    L->old_alias = in;
     LW_HIP(hipMemcpyAsync(L->rho_old, L->rho, c * 4, hipMemcpyDeviceToDevice, L->stream));
-    LW_HIP(hipMemcpyAsync(L->vel_old, L->vel[in], c * 3 * 4, hipMemcpyDeviceToDevice, L->stream));
     return LUDWIG_OK;
 }
 
@@ -802,6 +858,12 @@ int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int6
 {
     if (!L || (n > 0 && (!index_dev || !src_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
     if (n == 0) return LUDWIG_OK;
+    {
+        const bool aliased = L->old_alias >= 0;
+        const int r = before_external_write(L, field);
+        if (r) return r;
+        if (aliased && L->old_alias < 0 && hip_stream && (hipStream_t)hip_stream != L->stream) LW_HIP(hipStreamSynchronize(L->stream));
+    }
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be unpacked", field);
     LW_HIP(hipSetDevice(L->device));

@@ -89,9 +89,8 @@ def slice_level_fields(view: LocalView, source: BlockLevel) -> None:
         # every rank of a Bouzidi level stores f_post_collision (its ghosts may be asked for it)
         lvl.f_post_collision = np.zeros((B, B, B, lvl.n_blocks, 27), dtype=np.float32, order="F")
         lvl.f_post_collision[...] = source.f_post_collision[:, :, :, g] if source.f_post_collision.size > 27 else 0.0
-        if lvl.n_boundary_cells == 0:
-            # keep the store of f_post_collision alive on this rank: a peer's Bouzidi cells may read our face layer
-            lvl.force_post_collision = True
+        # keep the store of f_post_collision alive in every block of this rank: a peer's Bouzidi cells may read our face layer
+        lvl.force_post_collision = True
 
 
 def _source_of(cx: int, cy: int, cz: int):

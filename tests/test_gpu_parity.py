@@ -28,6 +28,13 @@ def run_both(grids, params, steps, u, batch=None):
     return dev
 
 
+def post_collision_blocks(g):
+    m = np.zeros(g.n_blocks, dtype=bool)
+    nb = np.asarray(g.neighbor_table)[np.unique(g.bouzidi_cell_block.astype(np.int64) - 1)]
+    m[nb[nb > 0] - 1] = True
+    return m
+
+
 def compare(grids, dev, steps, exact=True):
     for i, (g, d) in enumerate(zip(grids, dev)):
         fn, vn = oracle.newest_buffers(i, steps)
@@ -39,6 +46,11 @@ def compare(grids, dev, steps, exact=True):
         for name in names:
             a, b = d.download(name), getattr(g, name)
             assert np.isfinite(b).all(), f"oracle produced non-finite {name}"
+            if name == "f_post_collision" and not getattr(g, "force_post_collision", False):
+                # written only where it has a reader: blocks holding a Bouzidi cell and their neighbours (include/ludwig_hip.h)
+                m = post_collision_blocks(g)
+                assert 0 < m.sum()
+                a, b = a[:, :, :, m], b[:, :, :, m]
             if exact:
                 bad = np.argwhere(a != b)
                 assert bad.size == 0, (f"level {i + 1} {name}: {bad.shape[0]} elements differ, first at {bad[0]}, "
@@ -154,3 +166,54 @@ def test_tunnel_wall_model(gpu, levels):
     steps = 3
     dev = run_both(grids, params, steps, 0.05)
     compare(grids, dev, steps, exact=False)
+
+
+def test_saved_old_state_survives_steps_without_a_new_save(gpu):
+    """copy_to_old! is served without copying f / vel (the step never writes its input buffers). The saved state must
+    still read back as the reference's copy would - right after the save, after the step that follows it, and after a
+    further step that overwrites the buffer it was aliased to (the library then gives it its own storage first)."""
+    from open_ludwig_amd.physics import perform_timestep_v2
+    grids, params = cases.tunnel_with_sphere((4, 2, 2), levels=1, wall_model=False, temporal=True)
+    g = grids[0]
+    cases.init_perturbed(g, seed=3)
+    d = adapt(g, 0)
+    saved_f, saved_v, saved_r = g.f.copy(), g.vel.copy(), g.rho.copy()      # t_sub = 2 is even: input buffers are f / vel
+    d.copy_to_old(2)
+    for name, want in (("f_old", saved_f), ("vel_old", saved_v), ("rho_old", saved_r)):
+        assert np.array_equal(d.download(name), want), name
+    perform_timestep_v2(d, None, np.float32(0.5), np.float32(0.04), params, 2, np.float32(0.0))
+    assert np.array_equal(d.download("f_old"), saved_f) and np.array_equal(d.download("f"), saved_f)
+    perform_timestep_v2(d, None, np.float32(0.5), np.float32(0.04), params, 3, np.float32(0.0))     # writes f: the aliased buffer
+    assert not np.array_equal(d.download("f"), saved_f)
+    for name, want in (("f_old", saved_f), ("vel_old", saved_v), ("rho_old", saved_r)):
+        assert np.array_equal(d.download(name), want), name
+    # an upload into the aliased buffer must not change the saved state either
+    d.copy_to_old(4)
+    now_f = d.download("f")
+    d.upload("f", np.zeros_like(now_f))
+    assert np.array_equal(d.download("f_old"), now_f) and not d.download("f").any()
+    d.close()
+
+
+def test_post_collision_store_modes(gpu):
+    """Default: f_post_collision is written only in blocks that hold or touch a Bouzidi cell (elsewhere the store is dead:
+    src/bouzidi_kernel.jl:44-77 is its only reader). store_post_collision_everywhere restores the reference's full array.
+    Either way the populations are the same."""
+    results = []
+    for everywhere in (False, True):
+        grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=2, wall_model=False, temporal=True)
+        for g in grids:
+            g.force_post_collision = everywhere
+        dev = run_both(grids, params, 3, 0.05)
+        fin, d = grids[-1], dev[-1]
+        m = post_collision_blocks(fin)
+        assert 0 < m.sum() < fin.n_blocks
+        fp = d.download("f_post_collision")
+        assert np.array_equal(fp[:, :, :, m], fin.f_post_collision[:, :, :, m])
+        if everywhere:
+            assert np.array_equal(fp, fin.f_post_collision)
+        else:
+            assert not fp[:, :, :, ~m].any(), "blocks without a reader keep their initial zeros"
+        results.append(d.download("f"))
+        compare(grids, dev, 3)
+    assert np.array_equal(results[0], results[1])
