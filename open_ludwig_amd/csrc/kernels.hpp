@@ -538,52 +538,57 @@ __global__ __launch_bounds__(256) LW_WAVES_ATTR void k_stream_collide(const SCPa
     const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
 
     // ---- pull-stream, reference src/physics_kernels.jl:62-149 ----
+    // All 27 loads are issued first, branch-free (a lane whose source block is missing reads the same cell of its own block
+    // instead: in bounds, value unused), so they are in flight together; only then the missing-source lanes are patched.
     float fs[Q];
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
         const int sel = source_block<k>(nbr, l);
-        const uint32_t off = (uint32_t)sel * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
-        const float *fk = p.f_in + p.sk * k;
-        if constexpr (!GENERAL) {
-            fs[k] = ld_f32(fk, off);
-        } else {
-            float val;
-            if (sel >= 0) {
-                val = ld_f32(fk, off);
-            } else {
-                // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
-                const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
-                const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
-                const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
-                const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
-                const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
-                if (is_inlet) {
-                    const float noise = p.inlet_turbulence > 0.0f
-                                            ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
-                                            : 0.0f;
-                    const float u_inst = p.u_inlet + noise;
-                    const float cu_in = (float)cx * u_inst;
-                    val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
-                } else if (is_outlet) {
-                    const float cu_out = (float)cx * p.u_inlet;
-                    val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
-                } else if (is_y_min && p.is_symmetric == 1) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
-                } else if (is_y_min || is_y_max) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
-                } else if (is_z_min || is_z_max) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
-                } else if (p.is_level_1 == 0) {
-                    // value computed by k_interface_links for exactly this (cell, k) link (same function, same inputs)
-                    val = p.f_iface[((size_t)k * p.n_iface_blocks + meta[NBR_GBI]) * CELLS + (own_bytes >> 2) - (size_t)b * CELLS];
-                } else {
-                    val = WEIGHT(k);
+        const int safe = GENERAL ? (sel >= 0 ? sel : b) : sel;
+        const uint32_t off = (uint32_t)safe * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
+        fs[k] = ld_f32(p.f_in + p.sk * k, off);
+    });
+    if constexpr (GENERAL) {
+        // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
+        const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
+        const float *iface_own = p.is_level_1 == 0 ? p.f_iface + (size_t)meta[NBR_GBI] * CELLS + ((own_bytes >> 2) - (size_t)b * CELLS) : nullptr;
+        static_for<0, Q>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+            if constexpr (k != 13) {
+                if (source_block<k>(nbr, l) < 0) {
+                    const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
+                    const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
+                    const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
+                    const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
+                    float val;
+                    if (is_inlet) {
+                        const float noise = p.inlet_turbulence > 0.0f
+                                                ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
+                                                : 0.0f;
+                        const float u_inst = p.u_inlet + noise;
+                        const float cu_in = (float)cx * u_inst;
+                        val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
+                    } else if (is_outlet) {
+                        const float cu_out = (float)cx * p.u_inlet;
+                        val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
+                    } else if (is_y_min && p.is_symmetric == 1) {
+                        val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                    } else if (is_y_min || is_y_max) {
+                        val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                    } else if (is_z_min || is_z_max) {
+                        val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
+                    } else if (p.is_level_1 == 0) {
+                        // value computed by k_interface_links for exactly this (cell, k) link (same function, same inputs)
+                        val = iface_own[(size_t)k * p.n_iface_blocks * CELLS];
+                    } else {
+                        val = WEIGHT(k);
+                    }
+                    fs[k] = val;
                 }
             }
-            fs[k] = val;
-        }
-    });
+        });
+    }
     // previous-step velocity of the 6 face neighbours (WALE stencil) - issued with the pulls so that all loads of the
     // wave are in flight together; reference src/physics_utils.jl:72-83
     float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
@@ -769,93 +774,82 @@ struct CornerRef {
     int64_t c;       // cell offset in the parent arrays, -1 = invalid corner
 };
 
-constexpr int IFACE_SOURCES_PER_WG = 32;     // 8 lanes per source cell, 256 threads
-
-__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const int4 *__restrict__ sources, int n_sources,
-                                                          const int2 *__restrict__ links)
+// Pass 1, one thread per SOURCE cell (a fine-grid cell just outside this level's blocks): trilinear rho / u of
+// reference src/physics_interpolation.jl:64-124 - the same for every population pulled from that cell, so evaluated once.
+// The parent-cell offsets of the 8 corners and the weights are static (host, build_interface_links).
+__global__ __launch_bounds__(256) void k_interface_sources(const SCParams p, const int4 *__restrict__ corners, const float4 *__restrict__ weights,
+                                                            float4 *__restrict__ mac, int n_sources)
 {
-    // 8 lanes per SOURCE cell (a fine-grid cell just outside this level's blocks). Lane n fetches corner n of the
-    // trilinear stencil (rho / u of reference src/physics_interpolation.jl:110-124 are the same for every population
-    // pulled from the source, so they are fetched once); the 8 corners meet in LDS; then the lanes share the source's
-    // links, one f interpolation per link. Every lane evaluates the full expressions of interpolate_with_rescaling on all
-    // 8 corners in the reference's order: bit-identical to the inline call, only the latency chain is 8x shorter.
-    __shared__ float sh_v[IFACE_SOURCES_PER_WG][8][4];
-    __shared__ int sh_c[IFACE_SOURCES_PER_WG][8];
-    const int g = threadIdx.x >> 3, n = threadIdx.x & 7;
-    const int i = blockIdx.x * IFACE_SOURCES_PER_WG + g;
-    const bool live = i < n_sources;
-    const int4 s = live ? sources[i] : make_int4(1, 1, 1, 0);      // fine_gx, fine_gy, fine_gz, first link
-    const int last = live ? sources[i + 1].w : 0;                    // sentinel entry closes the last segment
-    const float px_cont = ((float)s.x - 0.5f) * 0.5f, py_cont = ((float)s.y - 0.5f) * 0.5f, pz_cont = ((float)s.z - 0.5f) * 0.5f;
-    int px0 = (int)floorf(px_cont), py0 = (int)floorf(py_cont), pz0 = (int)floorf(pz_cont);
-    const int px1 = px0 + 1, py1 = py0 + 1, pz1 = pz0 + 1;
-    const float wx = px_cont - (float)px0, wy = py_cont - (float)py0, wz = pz_cont - (float)pz0;
-    px0 = max(1, px0); py0 = max(1, py0); pz0 = max(1, pz0);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_sources) return;
+    const int4 c0 = corners[2 * i], c1 = corners[2 * i + 1];
+    const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float4 w = weights[i];
     const bool blend = p.use_temporal == 1 && p.temporal_weight < 0.99f;
     const float tw = p.temporal_weight;
-    {                                                // corner order 000,100,010,110,001,101,011,111
-        const int pgx = (n & 1) ? px1 : px0, pgy = (n & 2) ? py1 : py0, pgz = (n & 4) ? pz1 : pz0;
-        const int pbx = (pgx - 1) / BS + 1, pby = (pgy - 1) / BS + 1, pbz = (pgz - 1) / BS + 1;
-        int c = -1;
-        float r = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f;           // (w_k, 1, 0, 0, 0, false) default
-        if (live && pbx >= 1 && pbx <= p.pdim_x && pby >= 1 && pby <= p.pdim_y && pbz >= 1 && pbz <= p.pdim_z) {
-            const int32_t pb = p.pptr[(int64_t)(pbx - 1) + (int64_t)p.pdim_x * ((int64_t)(pby - 1) + (int64_t)p.pdim_y * (pbz - 1))];
-            if (pb > 0) {
-                c = ((pgx - 1) % BS) + 8 * ((pgy - 1) % BS) + 64 * ((pgz - 1) % BS) + 512 * (pb - 1);
-                const float rn = p.prho_new[c], un = p.pvel_new[c], vn = p.pvel_new[c + p.psk], wn = p.pvel_new[c + 2 * p.psk];
-                if (blend) {
-                    r = p.prho_old[c] * (1.0f - tw) + rn * tw;
-                    ux = p.pvel_old[c] * (1.0f - tw) + un * tw;
-                    uy = p.pvel_old[c + p.psk] * (1.0f - tw) + vn * tw;
-                    uz = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + wn * tw;
-                } else {
-                    r = rn; ux = un; uy = vn; uz = wn;
-                }
-            }
-        }
-        sh_c[g][n] = c;
-        sh_v[g][n][0] = r; sh_v[g][n][1] = ux; sh_v[g][n][2] = uy; sh_v[g][n][3] = uz;
-    }
-    __syncthreads();
-    if (!live) return;
-    int cc[8];
     float rho_c[8], ux_c[8], uy_c[8], uz_c[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-        cc[m] = sh_c[g][m];
-        rho_c[m] = sh_v[g][m][0]; ux_c[m] = sh_v[g][m][1]; uy_c[m] = sh_v[g][m][2]; uz_c[m] = sh_v[g][m][3];
+    for (int n = 0; n < 8; ++n) {
+        rho_c[n] = 1.0f; ux_c[n] = 0.0f; uy_c[n] = 0.0f; uz_c[n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
+        if (cc[n] >= 0) {
+            const int c = cc[n];
+            const float rn = p.prho_new[c], un = p.pvel_new[c], vn = p.pvel_new[c + p.psk], wn = p.pvel_new[c + 2 * p.psk];
+            if (blend) {
+                rho_c[n] = p.prho_old[c] * (1.0f - tw) + rn * tw;
+                ux_c[n] = p.pvel_old[c] * (1.0f - tw) + un * tw;
+                uy_c[n] = p.pvel_old[c + p.psk] * (1.0f - tw) + vn * tw;
+                uz_c[n] = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + wn * tw;
+            } else {
+                rho_c[n] = rn; ux_c[n] = un; uy_c[n] = vn; uz_c[n] = wn;
+            }
+        }
     }
     // invalid corners take corner 000's tuple (which may itself be the default), reference :100-107
 #pragma unroll
-    for (int m = 1; m < 8; ++m)
-        if (cc[m] < 0) { rho_c[m] = rho_c[0]; ux_c[m] = ux_c[0]; uy_c[m] = uy_c[0]; uz_c[m] = uz_c[0]; }
-    const float rho_int = trilin(rho_c[0], rho_c[1], rho_c[2], rho_c[3], rho_c[4], rho_c[5], rho_c[6], rho_c[7], wx, wy, wz);
-    const float ux_int = trilin(ux_c[0], ux_c[1], ux_c[2], ux_c[3], ux_c[4], ux_c[5], ux_c[6], ux_c[7], wx, wy, wz);
-    const float uy_int = trilin(uy_c[0], uy_c[1], uy_c[2], uy_c[3], uy_c[4], uy_c[5], uy_c[6], uy_c[7], wx, wy, wz);
-    const float uz_int = trilin(uz_c[0], uz_c[1], uz_c[2], uz_c[3], uz_c[4], uz_c[5], uz_c[6], uz_c[7], wx, wy, wz);
+    for (int n = 1; n < 8; ++n)
+        if (cc[n] < 0) { rho_c[n] = rho_c[0]; ux_c[n] = ux_c[0]; uy_c[n] = uy_c[0]; uz_c[n] = uz_c[0]; }
+    mac[i] = make_float4(trilin(rho_c[0], rho_c[1], rho_c[2], rho_c[3], rho_c[4], rho_c[5], rho_c[6], rho_c[7], w.x, w.y, w.z),
+                         trilin(ux_c[0], ux_c[1], ux_c[2], ux_c[3], ux_c[4], ux_c[5], ux_c[6], ux_c[7], w.x, w.y, w.z),
+                         trilin(uy_c[0], uy_c[1], uy_c[2], uy_c[3], uy_c[4], uy_c[5], uy_c[6], uy_c[7], w.x, w.y, w.z),
+                         trilin(uz_c[0], uz_c[1], uz_c[2], uz_c[3], uz_c[4], uz_c[5], uz_c[6], uz_c[7], w.x, w.y, w.z));
+}
+
+// Pass 2, one thread per LINK (cell, population k): f_k interpolated over the same 8 corners, equilibrium from pass 1's
+// moments, non-equilibrium rescaled (reference src/physics_interpolation.jl:110-135). Expression by expression the
+// reference's interpolate_with_rescaling, so the value is bit-identical to the inline call.
+__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const int4 *__restrict__ corners, const float4 *__restrict__ weights,
+                                                          const float4 *__restrict__ mac, const int4 *__restrict__ links, int n_links)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n_links) return;
+    const int4 l = links[j];
+    const int cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5, src = l.z;
+    const int4 c0 = corners[2 * src], c1 = corners[2 * src + 1];
+    const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    const float4 w = weights[src];
+    const float4 m = mac[src];
+    const bool blend = p.use_temporal == 1 && p.temporal_weight < 0.99f;
+    const float tw = p.temporal_weight;
+    const float w_k = weight_rt(k);
+    const int64_t koff = p.psk * k;
+    float fc[8];
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        fc[n] = w_k;
+        if (cc[n] >= 0) {
+            const float fn = p.pf_new[(int64_t)cc[n] + koff];
+            fc[n] = blend ? p.pf_old[(int64_t)cc[n] + koff] * (1.0f - tw) + fn * tw : fn;
+        }
+    }
+#pragma unroll
+    for (int n = 1; n < 8; ++n)
+        if (cc[n] < 0) fc[n] = fc[0];
+    const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], w.x, w.y, w.z);
+    const float feq_int = calculate_equilibrium(m.x, m.y, m.z, m.w, w_k, (float)(k % 3 - 1), (float)((k / 3) % 3 - 1), (float)(k / 9 - 1));
+    const float f_neq = f_int - feq_int;
     const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
     const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
-    for (int j = s.w + n; j < last; j += 8) {
-        const int2 l = links[j];
-        const int cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5;
-        const float w_k = weight_rt(k);
-        float fc[8];
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            fc[m] = w_k;
-            if (cc[m] >= 0) {
-                const float fn = p.pf_new[(int64_t)cc[m] + p.psk * k];
-                fc[m] = blend ? p.pf_old[(int64_t)cc[m] + p.psk * k] * (1.0f - tw) + fn * tw : fn;
-            }
-        }
-#pragma unroll
-        for (int m = 1; m < 8; ++m)
-            if (cc[m] < 0) fc[m] = fc[0];
-        const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], wx, wy, wz);
-        const float feq_int = calculate_equilibrium(rho_int, ux_int, uy_int, uz_int, w_k, (float)(k % 3 - 1), (float)((k / 3) % 3 - 1), (float)(k / 9 - 1));
-        const float f_neq = f_int - feq_int;
-        p.f_iface[((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell] = feq_int + f_neq * scale;
-    }
+    p.f_iface[((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell] = feq_int + f_neq * scale;
 }
 
 // ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----

@@ -75,8 +75,12 @@ struct LudwigLevel {
     // coarse -> fine interface pass (levels >= 2): links per part, built lazily for the global box of the first step
     int n_iface_blocks = 0;
     float *f_iface = nullptr;
-    int2 *links[N_PARTS] = {};
-    int4 *sources[N_PARTS] = {};        // per source cell: fine gx, gy, gz, first link; one sentinel at the end
+    int4 *links[N_PARTS] = {};           // per link: (block << 9) | cell, (gbi << 5) | k, source index
+    int4 *sources[N_PARTS] = {};        // per source cell: 8 parent-cell offsets of its trilinear stencil (-1 = absent), 2 x int4
+    float4 *source_w[N_PARTS] = {};     // per source cell: interpolation weights wx, wy, wz
+    float4 *source_mac[N_PARTS] = {};   // per source cell, rewritten every pass: interpolated rho, ux, uy, uz
+    const LudwigLevel *iface_parent = nullptr;
+    std::vector<int32_t> h_block_pointer;
     int n_links[N_PARTS] = {};
     int n_sources[N_PARTS] = {};
     int iface_dims[3] = {-1, -1, -1};
@@ -317,9 +321,13 @@ int default_items(LudwigLevel *L, int part)
 
 // Links (cell, population) of the interface blocks whose source block is missing and for which the reference's
 // domain-edge chain (src/physics_kernels.jl:88-140) selects the parent interpolation: source inside the global box.
-int build_interface_links(LudwigLevel *L, int nx_g, int ny_g, int nz_g)
+int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, int ny_g, int nz_g)
 {
-    if (L->iface_dims[0] == nx_g && L->iface_dims[1] == ny_g && L->iface_dims[2] == nz_g) return LUDWIG_OK;
+    // Everything about a link that does not depend on the flow is fixed here, once: which (cell, population) pairs pull
+    // from outside the level (reference src/physics_kernels.jl:122-137), and for each such source cell the 8 parent cells
+    // of its trilinear stencil and the weights (reference src/physics_interpolation.jl:29-62: px_cont, floor, +1 before
+    // the clamp to 1, block lookup through the parent's block_pointer).
+    if (L->iface_parent == parent && L->iface_dims[0] == nx_g && L->iface_dims[1] == ny_g && L->iface_dims[2] == nz_g) return LUDWIG_OK;
     LW_HIP(hipStreamSynchronize(L->stream));
     struct Link { int64_t key; int sx, sy, sz; int2 e; };
     std::vector<Link> raw[N_PARTS];
@@ -346,29 +354,61 @@ int build_interface_links(LudwigLevel *L, int nx_g, int ny_g, int nz_g)
     }
     for (int a2 = 0; a2 < N_PARTS; ++a2) {
         std::stable_sort(raw[a2].begin(), raw[a2].end(), [](const Link &u, const Link &v) { return u.key < v.key; });
-        std::vector<int2> links;
-        std::vector<int4> src;
+        std::vector<int4> links;       // (block << 9) | cell, (gbi << 5) | k, source index, unused
+        std::vector<int4> corners;     // 2 per source
+        std::vector<float4> weights;
         for (size_t i = 0; i < raw[a2].size(); ++i) {
-            if (i == 0 || raw[a2][i].key != raw[a2][i - 1].key) src.push_back(make_int4(raw[a2][i].sx, raw[a2][i].sy, raw[a2][i].sz, (int)i));
-            links.push_back(raw[a2][i].e);
+            const Link &l = raw[a2][i];
+            if (i == 0 || l.key != raw[a2][i - 1].key) {
+                const float pc[3] = {((float)l.sx - 0.5f) * 0.5f, ((float)l.sy - 0.5f) * 0.5f, ((float)l.sz - 0.5f) * 0.5f};
+                int p0[3], p1[3];
+                float w[3];
+                for (int d = 0; d < 3; ++d) {
+                    p0[d] = (int)floorf(pc[d]);
+                    p1[d] = p0[d] + 1;
+                    w[d] = pc[d] - (float)p0[d];
+                    p0[d] = std::max(1, p0[d]);
+                }
+                int cc[8];
+                for (int n = 0; n < 8; ++n) {        // corner order 000,100,010,110,001,101,011,111
+                    const int pgx = (n & 1) ? p1[0] : p0[0], pgy = (n & 2) ? p1[1] : p0[1], pgz = (n & 4) ? p1[2] : p0[2];
+                    const int pbx = (pgx - 1) / BS + 1, pby = (pgy - 1) / BS + 1, pbz = (pgz - 1) / BS + 1;
+                    cc[n] = -1;
+                    if (pbx >= 1 && pbx <= parent->gdx && pby >= 1 && pby <= parent->gdy && pbz >= 1 && pbz <= parent->gdz) {
+                        const int32_t pb = parent->h_block_pointer[(size_t)(pbx - 1) + (size_t)parent->gdx * ((size_t)(pby - 1) + (size_t)parent->gdy * (pbz - 1))];
+                        if (pb > 0) cc[n] = ((pgx - 1) % BS) + 8 * ((pgy - 1) % BS) + 64 * ((pgz - 1) % BS) + 512 * (pb - 1);
+                    }
+                }
+                corners.push_back(make_int4(cc[0], cc[1], cc[2], cc[3]));
+                corners.push_back(make_int4(cc[4], cc[5], cc[6], cc[7]));
+                weights.push_back(make_float4(w[0], w[1], w[2], 0.0f));
+            }
+            links.push_back(make_int4(l.e.x, l.e.y, (int)weights.size() - 1, 0));
         }
-        const int nsrc = (int)src.size();
-        src.push_back(make_int4(0, 0, 0, (int)links.size()));     // sentinel
-        if (L->links[a2]) { (void)hipFree(L->links[a2]); L->links[a2] = nullptr; }
-        if (L->sources[a2]) { (void)hipFree(L->sources[a2]); L->sources[a2] = nullptr; }
+        // launch order of the links: population by population, sources in (z, y, x) order inside. Neighbouring lanes then
+        // read neighbouring parent cells of ONE population array (a few 128-B lines per wave-load instead of ~30) and
+        // write neighbouring cells of f_iface.
+        std::stable_sort(links.begin(), links.end(), [](const int4 &u, const int4 &v) { return (u.y & 31) < (v.y & 31); });
+        void **owned[] = {(void **)&L->links[a2], (void **)&L->sources[a2], (void **)&L->source_w[a2], (void **)&L->source_mac[a2]};
+        for (void **q : owned)
+            if (*q) { (void)hipFree(*q); *q = nullptr; }
         L->n_links[a2] = (int)links.size();
-        L->n_sources[a2] = nsrc;
+        L->n_sources[a2] = (int)weights.size();
         if (!links.empty()) {
-            LW_HIP(hipMalloc((void **)&L->links[a2], links.size() * sizeof(int2)));
-            LW_HIP(hipMemcpy(L->links[a2], links.data(), links.size() * sizeof(int2), hipMemcpyHostToDevice));
-            LW_HIP(hipMalloc((void **)&L->sources[a2], src.size() * sizeof(int4)));
-            LW_HIP(hipMemcpy(L->sources[a2], src.data(), src.size() * sizeof(int4), hipMemcpyHostToDevice));
+            LW_HIP(hipMalloc((void **)&L->links[a2], links.size() * sizeof(int4)));
+            LW_HIP(hipMemcpy(L->links[a2], links.data(), links.size() * sizeof(int4), hipMemcpyHostToDevice));
+            LW_HIP(hipMalloc((void **)&L->sources[a2], corners.size() * sizeof(int4)));
+            LW_HIP(hipMemcpy(L->sources[a2], corners.data(), corners.size() * sizeof(int4), hipMemcpyHostToDevice));
+            LW_HIP(hipMalloc((void **)&L->source_w[a2], weights.size() * sizeof(float4)));
+            LW_HIP(hipMemcpy(L->source_w[a2], weights.data(), weights.size() * sizeof(float4), hipMemcpyHostToDevice));
+            LW_HIP(hipMalloc((void **)&L->source_mac[a2], weights.size() * sizeof(float4)));
         }
     }
     if (!L->f_iface && L->n_iface_blocks > 0) {
         LW_HIP(hipMalloc((void **)&L->f_iface, (size_t)L->n_iface_blocks * CELLS * Q * sizeof(float)));
         L->device_bytes += (int64_t)L->n_iface_blocks * CELLS * Q * 4;
     }
+    L->iface_parent = parent;
     L->iface_dims[0] = nx_g; L->iface_dims[1] = ny_g; L->iface_dims[2] = nz_g;
     return LUDWIG_OK;
 }
@@ -437,13 +477,15 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
     if (parent && L->n_items[part][1] > 0) {
         // coarse -> fine interface pass for the general blocks of this part (reference src/physics_kernels.jl:122-137)
-        const int r = build_interface_links(L, p.nx_g, p.ny_g, p.nz_g);
+        const int r = build_interface_links(L, parent, p.nx_g, p.ny_g, p.nz_g);
         if (r) return r;
         p.f_iface = L->f_iface;
         p.n_iface_blocks = L->n_iface_blocks;
         if (L->n_links[part] > 0) {
-            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_sources[part] + IFACE_SOURCES_PER_WG - 1) / IFACE_SOURCES_PER_WG)), dim3(256), 0,
-                               L->stream, p, L->sources[part], L->n_sources[part], L->links[part]);
+            hipLaunchKernelGGL(k_interface_sources, dim3((unsigned)((L->n_sources[part] + 255) / 256)), dim3(256), 0, L->stream, p,
+                               L->sources[part], L->source_w[part], L->source_mac[part], L->n_sources[part]);
+            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_links[part] + 255) / 256)), dim3(256), 0, L->stream, p,
+                               L->sources[part], L->source_w[part], L->source_mac[part], L->links[part], L->n_links[part]);
             LW_HIP(hipGetLastError());
         }
     }
@@ -524,6 +566,8 @@ void ludwig_level_destroy(LudwigLevel *L)
             if (L->items[a][c]) (void)hipFree(L->items[a][c]);
         if (L->links[a]) (void)hipFree(L->links[a]);
         if (L->sources[a]) (void)hipFree(L->sources[a]);
+        if (L->source_w[a]) (void)hipFree(L->source_w[a]);
+        if (L->source_mac[a]) (void)hipFree(L->source_mac[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
     delete L;
@@ -635,7 +679,10 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
         else LW_HIP(hipMemsetAsync(L->sponge, 0, c * 4, L->stream));
         if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, c * 4, hipMemcpyHostToDevice, L->stream));
         else if ((r = fill(L, L->wall_dist, L->sk, 100.0f))) return r;
-        if (L->block_pointer) LW_HIP(hipMemcpyAsync(L->block_pointer, h->block_pointer, nptr * 4, hipMemcpyHostToDevice, L->stream));
+        if (L->block_pointer) {
+            LW_HIP(hipMemcpyAsync(L->block_pointer, h->block_pointer, nptr * 4, hipMemcpyHostToDevice, L->stream));
+            L->h_block_pointer.assign(h->block_pointer, h->block_pointer + nptr);
+        }
         if (L->bouzidi_enabled) {
             LW_HIP(hipMemcpyAsync(L->q_map, h->bouzidi_q_map, c * Q * 2, hipMemcpyHostToDevice, L->stream));
             std::vector<int32_t> cb((size_t)L->n_bc);
