@@ -108,7 +108,7 @@ def main():
     stream = torch.cuda.current_stream()
 
     if world == 1:
-        grids, params = cases.periodic_box((nb, nb, nb))
+        grids, params = cases.periodic_box((nb, nb, nb), upload_only=True)
         level = adapt(grids[0], local_rank)
         coords = np.asarray(grids[0].active_block_coords)
         del grids

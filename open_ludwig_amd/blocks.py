@@ -75,6 +75,8 @@ def build_neighbor_table(active_coords: Sequence[Tuple[int, int, int]], bx_max: 
 
 
 def _f(shape, fill=0.0, dtype=np.float32):
+    if fill == 0.0:
+        return np.zeros(shape, dtype=dtype, order="F")      # untouched pages: a 256^3 level is several GB of these
     a = np.empty(shape, dtype=dtype, order="F")
     a[...] = fill
     return a

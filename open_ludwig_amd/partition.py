@@ -669,7 +669,7 @@ def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int
     nbg = tuple(nb_per_rank[i] * grid[i] for i in range(3))
     coords, table, owner = periodic_box_topology(nbg, grid)
     view = build_local_level(1, coords, table, owner, rank, tau)
-    cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), u0)
+    cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), u0, share_ab_buffers=True)    # host level is only uploaded
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)
     n_global = len(coords)
