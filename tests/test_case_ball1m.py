@@ -168,3 +168,59 @@ def test_ball1m_result_files(gpu, ball_setup, tmp_path):
     assert int((d["Obstacle"] == 1).sum()) == sum(int(grids[l].obstacle[:, :, :, b].sum()) for l, b in sel)
     s = read_vtu(str(tmp_path / "surface_000032.vtu"))
     assert s["n_cells"] == 20480 and s["MappingQuality"].mean() > 0.9 and np.isfinite(s["Pressure_Pa"]).all()
+
+
+# ---- second external anchor: CASES/ball1m as shipped (Re 9.87 M, N = 55), the run whose outputs the reference keeps ----
+RE10M = {"basic": {"num_levels": 4}}      # the log of that run says "4 levels" (RESULTS_SPHERE_RE10M.txt:51)
+
+
+@pytest.fixture(scope="module")
+def ball_re10m_setup():
+    cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"), RE10M)
+    return cfg, pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
+
+
+def test_re10m_setup_matches_reference_log(ball_re10m_setup):
+    cfg, (grids, mesh, params, rep) = ball_re10m_setup
+    js = json.load(open(os.path.join(G, "sphere_re10m_setup.json")))
+    assert params.num_levels == 4 and [params.bx_max, params.by_max, params.bz_max] == js["level1_grid"]
+    assert rep.level_blocks == js["level_blocks"] and rep.halo_blocks_added[1:] == js["halo_blocks_added"]
+    assert rep.flood_fill_filled == js["flood_fill_interior_voxels"]
+    assert rep.bouzidi_cells == [js["bouzidi_boundary_cells_level4"]]
+    assert [round(100 * v, 1) for v in rep.sponge_fraction] == js["sponge_percent"]
+    assert [round(v, 3) for v in rep.sponge_max] == js["sponge_max"]
+    assert rep.near_wall_cells[1] == js["near_wall_cells_level2"]          # the other levels' counts come from a racy counter
+    assert [f"{float(t):.6f}" for t in params.tau_levels] == js["tau_levels"]
+    assert [round(float(v), 3) for v in params.mesh_offset] == js["mesh_offset"]
+    assert round(params.dx_fine, 6) == js["dx_fine"]
+    assert "%.6e" % (params.rho_physical * params.velocity_scale ** 2) == "2.981378e+07"
+    assert round(sum(g.n_blocks for g in grids) * 512 / 1e6, 2) == js["total_cells_millions"]
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_reference_forces_csv_re10m(gpu, ball_re10m_setup, tmp_path):
+    """The reference's kept forces.csv (CUDA run, FMA contraction, Float32 atomics) against this engine + forces + CSV
+    writer, steps 400...2000 of the ramp: drag force to 5e-4 relative (observed <= 3e-4, mostly ~5e-5), its viscous part to
+    1e-3, Cd to 1e-4 absolute, side/lift coefficients to 1e-4 absolute; physical time and inlet speed columns exactly."""
+    import copy
+    cfg, setup = ball_re10m_setup
+    cfg = copy.copy(cfg)
+    cfg.output_freq = 10 ** 9                         # no VTU here: the flow file of 3.9 M cells is ~100 MB
+    rows, _, params = case.run_case(cfg, case.HipStepper, steps=2000, setup=setup, out_dir=str(tmp_path))
+    ref = {int(l.split(",")[0]): l.strip().split(",") for l in open(os.path.join(G, "sphere_re10m_forces.csv")) if l[0].isdigit()}
+    mine = {int(l.split(",")[0]): l.strip().split(",") for l in open(tmp_path / "forces.csv") if l[0].isdigit()}
+    assert sorted(mine) == list(range(200, 2001, 200))
+    for s in range(400, 2001, 200):
+        a, b = mine[s], ref[s]
+        assert a[1] == b[1] and a[2] == b[2], "Time_s / U_inlet columns"
+        fx, fxr = float(a[3]), float(b[3])
+        assert abs(fx - fxr) <= 5e-4 * abs(fxr), (s, fx, fxr)
+        assert abs(float(a[7]) - float(b[7])) <= 1e-3 * abs(float(b[7])), (s, "Fx_v")
+        for col in (11, 12, 13):                       # Cd, Cl, Cs
+            assert abs(float(a[col]) - float(b[col])) <= 1e-4, (s, col, a[col], b[col])
+    conv = {int(l.split(",")[0]): l.strip().split(",") for l in open(os.path.join(G, "sphere_re10m_convergence.csv")) if l[0].isdigit()}
+    minec = {int(l.split(",")[0]): l.strip().split(",") for l in open(tmp_path / "convergence.csv") if l[0].isdigit()}
+    for s in range(400, 2001, 200):
+        assert minec[s][2] == conv[s][2] and minec[s][3] == conv[s][3], "Time_phys_s / U_inlet_lat text"
+        assert abs(float(minec[s][4]) - float(conv[s][4])) <= 2e-6, "rho_min"
+        assert abs(float(minec[s][6]) - float(conv[s][6])) <= 1.5e-4 and abs(float(minec[s][7]) - float(conv[s][7])) <= 1.5e-4
