@@ -38,8 +38,6 @@ struct SCParams {
     int64_t sk;               // population stride in elements = 512 * n_blocks
     // parent level (coarse -> fine interface), unused on level 1
     const float *pf_new, *pf_old, *prho_new, *prho_old, *pvel_new, *pvel_old;
-    const int32_t *pptr;      // parent block_pointer, 1-based, 0 = absent
-    int32_t pdim_x, pdim_y, pdim_z;
     int64_t psk;
     float tau, tau_parent, c_wale, nu_bg, u_inlet, inlet_turbulence, temporal_weight;
     int32_t is_level_1, is_symmetric, nx_g, ny_g, nz_g;
@@ -113,43 +111,8 @@ __device__ __forceinline__ float calculate_equilibrium(float rho, float ux, floa
     return rho * w_k * (1.0f + 3.0f * cu + 4.5f * cu * cu - 1.5f * usq);
 }
 
-// ---- coarse -> fine interface value, reference src/physics_interpolation.jl:16-138 ----
-struct Blend {
-    float f, rho, ux, uy, uz;
-    bool valid;
-};
-
-__device__ inline Blend get_blended(const SCParams &p, int pgx, int pgy, int pgz, int k, float w_k)
-{
-    const int pbx = (pgx - 1) / BS + 1, pby = (pgy - 1) / BS + 1, pbz = (pgz - 1) / BS + 1;
-    if (pbx >= 1 && pbx <= p.pdim_x && pby >= 1 && pby <= p.pdim_y && pbz >= 1 && pbz <= p.pdim_z) {
-        const int32_t pb = p.pptr[(int64_t)(pbx - 1) + (int64_t)p.pdim_x * ((int64_t)(pby - 1) + (int64_t)p.pdim_y * (pbz - 1))];
-        if (pb > 0) {
-            const int plx = (pgx - 1) % BS, ply = (pgy - 1) % BS, plz = (pgz - 1) % BS;   // 0-based
-            const int64_t c = (int64_t)plx + 8 * ply + 64 * plz + 512 * (int64_t)(pb - 1);
-            Blend r;
-            const float f_new = p.pf_new[c + p.psk * k];
-            const float rho_new = p.prho_new[c];
-            const float ux_new = p.pvel_new[c];
-            const float uy_new = p.pvel_new[c + p.psk];
-            const float uz_new = p.pvel_new[c + 2 * p.psk];
-            if (p.use_temporal == 1 && p.temporal_weight < 0.99f) {
-                const float tw = p.temporal_weight;
-                r.f = p.pf_old[c + p.psk * k] * (1.0f - tw) + f_new * tw;
-                r.rho = p.prho_old[c] * (1.0f - tw) + rho_new * tw;
-                r.ux = p.pvel_old[c] * (1.0f - tw) + ux_new * tw;
-                r.uy = p.pvel_old[c + p.psk] * (1.0f - tw) + uy_new * tw;
-                r.uz = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + uz_new * tw;
-                r.valid = true;
-                return r;
-            }
-            r.f = f_new; r.rho = rho_new; r.ux = ux_new; r.uy = uy_new; r.uz = uz_new; r.valid = true;
-            return r;
-        }
-    }
-    return Blend{w_k, 1.0f, 0.0f, 0.0f, 0.0f, false};
-}
-
+// ---- coarse -> fine interface value, reference src/physics_interpolation.jl:16-138: the trilinear kernel; the corner
+// fetch, the blend in time and the rescaling live in k_interface_sources / k_interface_links below ----
 __device__ __forceinline__ float trilin(float v000, float v100, float v010, float v110, float v001, float v101,
                                         float v011, float v111, float wx, float wy, float wz)
 {
@@ -160,35 +123,6 @@ __device__ __forceinline__ float trilin(float v000, float v100, float v010, floa
     const float c0 = c00 * (1.0f - wy) + c10 * wy;
     const float c1 = c01 * (1.0f - wy) + c11 * wy;
     return c0 * (1.0f - wz) + c1 * wz;
-}
-
-__device__ __noinline__ float interpolate_with_rescaling(const SCParams &p, int fine_gx, int fine_gy, int fine_gz, int k,
-                                                         float w_k, float cx, float cy, float cz)
-{
-    const float px_cont = ((float)fine_gx - 0.5f) * 0.5f;
-    const float py_cont = ((float)fine_gy - 0.5f) * 0.5f;
-    const float pz_cont = ((float)fine_gz - 0.5f) * 0.5f;
-    int px0 = (int)floorf(px_cont), py0 = (int)floorf(py_cont), pz0 = (int)floorf(pz_cont);
-    const int px1 = px0 + 1, py1 = py0 + 1, pz1 = pz0 + 1;   // before the clamp, as in the reference (:36-46)
-    const float wx = px_cont - (float)px0, wy = py_cont - (float)py0, wz = pz_cont - (float)pz0;
-    px0 = max(1, px0); py0 = max(1, py0); pz0 = max(1, pz0);
-
-    const Blend d000 = get_blended(p, px0, py0, pz0, k, w_k), d100 = get_blended(p, px1, py0, pz0, k, w_k);
-    const Blend d010 = get_blended(p, px0, py1, pz0, k, w_k), d110 = get_blended(p, px1, py1, pz0, k, w_k);
-    const Blend d001 = get_blended(p, px0, py0, pz1, k, w_k), d101 = get_blended(p, px1, py0, pz1, k, w_k);
-    const Blend d011 = get_blended(p, px0, py1, pz1, k, w_k), d111 = get_blended(p, px1, py1, pz1, k, w_k);
-    const Blend v000 = d000;
-    const Blend v100 = d100.valid ? d100 : v000, v010 = d010.valid ? d010 : v000, v110 = d110.valid ? d110 : v000;
-    const Blend v001 = d001.valid ? d001 : v000, v101 = d101.valid ? d101 : v000, v011 = d011.valid ? d011 : v000;
-    const Blend v111 = d111.valid ? d111 : v000;
-#define LW_TL(m) trilin(v000.m, v100.m, v010.m, v110.m, v001.m, v101.m, v011.m, v111.m, wx, wy, wz)
-    const float f_int = LW_TL(f), rho_int = LW_TL(rho), ux_int = LW_TL(ux), uy_int = LW_TL(uy), uz_int = LW_TL(uz);
-#undef LW_TL
-    const float feq_int = calculate_equilibrium(rho_int, ux_int, uy_int, uz_int, w_k, cx, cy, cz);
-    const float f_neq = f_int - feq_int;
-    const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
-    const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
-    return feq_int + f_neq * scale;
 }
 
 // ---- wall-model force, reference src/physics_kernels.jl:206-236 ----
@@ -760,19 +694,15 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
 // The reference evaluates interpolate_with_rescaling inline, for the few lanes of a refinement-edge block whose source
 // block is missing. Done that way on a 64-wide wavefront it is 27 divergent call sites at ~12 % lane utilisation and
 // took 86 % of the GPU time of a 3-level case (profiles/r01_ball1m_kernel_stats_before_interface_pass.csv). The links
-// that need it are a static property of the level (topology + global box), so the host lists them once and this kernel
-// evaluates one link per lane; the stream-collide kernel then loads the value. Same function, same inputs: bit-identical.
+// that need it are a static property of the level (topology + global box), so the host lists them once and two small
+// kernels evaluate them (per source cell, then per link); the stream-collide kernel loads the value. Same expressions on
+// the same inputs as the reference's interpolate_with_rescaling: bit-identical.
 __device__ __forceinline__ float weight_rt(int k)
 {
     const int cx = k % 3 - 1, cy = (k / 3) % 3 - 1, cz = k / 9 - 1;
     const int d2 = cx * cx + cy * cy + cz * cz;
     return d2 == 0 ? WEIGHT(13) : d2 == 1 ? WEIGHT(12) : d2 == 2 ? WEIGHT(9) : WEIGHT(0);
 }
-
-// corner data of one parent cell: macroscopic part (shared by all populations of a source cell)
-struct CornerRef {
-    int64_t c;       // cell offset in the parent arrays, -1 = invalid corner
-};
 
 // Pass 1, one thread per SOURCE cell (a fine-grid cell just outside this level's blocks): trilinear rho / u of
 // reference src/physics_interpolation.jl:64-124 - the same for every population pulled from that cell, so evaluated once.

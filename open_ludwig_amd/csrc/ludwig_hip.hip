@@ -56,7 +56,7 @@ struct LudwigLevel {
     float *rho = nullptr, *f_post = nullptr, *f_old = nullptr, *rho_old = nullptr, *vel_old = nullptr;
     uint8_t *obstacle = nullptr;
     float *sponge = nullptr, *wall_dist = nullptr;
-    int32_t *meta = nullptr, *block_pointer = nullptr;
+    int32_t *meta = nullptr;
     bool has_temporal = false, has_post = false, bouzidi_enabled = false;
     // copy_to_old! without the copies: a pull step never writes its input buffers, so after ludwig_save_old(t_sub) the saved
     // f / vel ARE f[in] / vel[in] until something else writes that buffer. old_alias = that buffer index, or -1 when the
@@ -80,7 +80,7 @@ struct LudwigLevel {
     float4 *source_w[N_PARTS] = {};     // per source cell: interpolation weights wx, wy, wz
     float4 *source_mac[N_PARTS] = {};   // per source cell, rewritten every pass: interpolated rho, ux, uy, uz
     const LudwigLevel *iface_parent = nullptr;
-    std::vector<int32_t> h_block_pointer;
+    std::vector<int32_t> h_block_pointer;   // [gdx,gdy,gdz] 1-based, 0 = absent (src/blocks.jl:111-114)
     int n_links[N_PARTS] = {};
     int n_sources[N_PARTS] = {};
     int iface_dims[3] = {-1, -1, -1};
@@ -328,6 +328,8 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
     // of its trilinear stencil and the weights (reference src/physics_interpolation.jl:29-62: px_cont, floor, +1 before
     // the clamp to 1, block lookup through the parent's block_pointer).
     if (L->iface_parent == parent && L->iface_dims[0] == nx_g && L->iface_dims[1] == ny_g && L->iface_dims[2] == nz_g) return LUDWIG_OK;
+    if (parent->h_block_pointer.size() != (size_t)parent->gdx * parent->gdy * parent->gdz)
+        return fail(LUDWIG_ERR_STATE, "parent level %d was created without block_pointer: its children cannot interpolate", parent->level_id);
     LW_HIP(hipStreamSynchronize(L->stream));
     struct Link { int64_t key; int sx, sy, sz; int2 e; };
     std::vector<Link> raw[N_PARTS];
@@ -451,8 +453,6 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.pf_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->f[parent->old_alias] : parent->f_old) : parent->f[pout];
         p.prho_old = parent->has_temporal ? parent->rho_old : parent->rho;
         p.pvel_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->vel[parent->old_alias] : parent->vel_old) : parent->vel[pout];
-        p.pptr = parent->block_pointer;
-        p.pdim_x = parent->gdx; p.pdim_y = parent->gdy; p.pdim_z = parent->gdz;
         p.psk = parent->sk;
         p.is_level_1 = 0;
     } else {
@@ -558,7 +558,7 @@ void ludwig_level_destroy(LudwigLevel *L)
     if (!L) return;
     (void)hipSetDevice(L->device);
     void *ptrs[] = {L->f[0], L->f[1], L->vel[0], L->vel[1], L->rho, L->f_post, L->f_old, L->rho_old, L->vel_old, L->obstacle,
-                    L->sponge, L->wall_dist, L->meta, L->block_pointer, L->q_map, L->cell_block, L->cell_x, L->cell_y, L->cell_z};
+                    L->sponge, L->wall_dist, L->meta, L->q_map, L->cell_block, L->cell_x, L->cell_y, L->cell_z};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (int a = 0; a < N_PARTS; ++a) {
@@ -624,7 +624,6 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     LW_TRY(dev_alloc(L, &L->wall_dist, c));
     LW_TRY(dev_alloc(L, &L->meta, nb * NBR_STRIDE));
     const size_t nptr = (size_t)h->grid_dim_x * h->grid_dim_y * h->grid_dim_z;
-    if (h->block_pointer && nptr > 0) LW_TRY(dev_alloc(L, &L->block_pointer, nptr));
     if (L->bouzidi_enabled) {
         LW_TRY(dev_alloc(L, &L->q_map, c * Q));
         LW_TRY(dev_alloc(L, &L->cell_block, (size_t)L->n_bc));
@@ -679,10 +678,8 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
         else LW_HIP(hipMemsetAsync(L->sponge, 0, c * 4, L->stream));
         if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, c * 4, hipMemcpyHostToDevice, L->stream));
         else if ((r = fill(L, L->wall_dist, L->sk, 100.0f))) return r;
-        if (L->block_pointer) {
-            LW_HIP(hipMemcpyAsync(L->block_pointer, h->block_pointer, nptr * 4, hipMemcpyHostToDevice, L->stream));
-            L->h_block_pointer.assign(h->block_pointer, h->block_pointer + nptr);
-        }
+        // block_pointer stays on the host: its only use is the static corner lookup of a child's interface links
+        if (h->block_pointer && nptr > 0) L->h_block_pointer.assign(h->block_pointer, h->block_pointer + nptr);
         if (L->bouzidi_enabled) {
             LW_HIP(hipMemcpyAsync(L->q_map, h->bouzidi_q_map, c * Q * 2, hipMemcpyHostToDevice, L->stream));
             std::vector<int32_t> cb((size_t)L->n_bc);
