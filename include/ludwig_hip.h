@@ -175,6 +175,26 @@ int  ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels,
 /* KernelAbstractions.synchronize(backend) (src/solver_control.jl:164) */
 int  ludwig_sync(const LudwigLevel *level);
 
+/* ---- surface stresses for the force diagnostics (the caller of the path on the output side) ----
+ * map_stresses_kernel! (src/forces/surface.jl:138-266, launched at :406-420): for every triangle the nearest fluid cell
+ * of the level (shells of radius 0..search_radius around the cell holding the triangle centre, scan order dz, dy, dx, the
+ * first strictly smaller distance wins, the search stops after a shell of radius > 1 once a cell was found), then
+ * p = (rho - 1) / 3 * pressure_scale and tau = rho * nu * u_t / d * stress_scale (compute_stress_from_cell :32-76).
+ * centers / normals: HOST [n_triangles * 3] Float32 (x, y, z per triangle, mesh coordinates: the offset is added here);
+ * outputs: HOST [n_triangles] Float32 each. vel_field: LUDWIG_VEL (what the reference reads, :412) or LUDWIG_VEL_TEMP.
+ * The integration (integrate_forces_kernel! :282-366) stays with the caller: it is a sum over these four arrays. */
+typedef struct LudwigSurfaceParams {
+    float   dx;                 /* level.dx                                  */
+    float   tau;                /* level.tau                                 */
+    float   offset_x, offset_y, offset_z;   /* params.mesh_offset            */
+    float   pressure_scale, stress_scale;
+    int32_t search_radius;      /* reference: 5 (src/main.jl:197)            */
+} LudwigSurfaceParams;
+
+int  ludwig_map_surface_stresses(const LudwigLevel *level, int vel_field, int32_t n_triangles, const float *centers,
+                                 const float *normals, const LudwigSurfaceParams *sp,
+                                 float *pressure, float *shear_x, float *shear_y, float *shear_z);
+
 /* ---- halo exchange helpers (no reference counterpart: the reference is single-device) ---- */
 /* dst[i] = field[index[i]] / field[index[i]] = src[i]; index, dst, src are DEVICE pointers, index holds element
  * offsets into the field in the reference layout. hip_stream: the stream to queue on (hipStream_t), NULL = the

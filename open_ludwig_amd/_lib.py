@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "ludwig_level_upload", "ludwig_level_download", "ludwig_level_field_ptr",
     "ludwig_init_equilibrium", "ludwig_step", "ludwig_stream_collide", "ludwig_bouzidi_correction",
     "ludwig_save_old", "ludwig_execute_timestep_batch", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
+    "ludwig_map_surface_stresses",
 ]
 
 
@@ -58,6 +59,13 @@ class StepFlags(C.Structure):
         ("sponge_blend_distributions", C.c_int32),
         ("c_wale", C.c_float), ("nu_sgs_background", C.c_float), ("inlet_turbulence", C.c_float),
         ("q_min_threshold", C.c_float),
+    ]
+
+
+class SurfaceParams(C.Structure):
+    _fields_ = [
+        ("dx", C.c_float), ("tau", C.c_float), ("offset_x", C.c_float), ("offset_y", C.c_float), ("offset_z", C.c_float),
+        ("pressure_scale", C.c_float), ("stress_scale", C.c_float), ("search_radius", C.c_int32),
     ]
 
 
@@ -103,6 +111,7 @@ def load() -> C.CDLL:
         "ludwig_sync": (C.c_int, [vp]),
         "ludwig_halo_pack": (C.c_int, [vp, i32, vp, i64, vp, vp]),
         "ludwig_halo_unpack": (C.c_int, [vp, i32, vp, i64, vp, vp]),
+        "ludwig_map_surface_stresses": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(SurfaceParams), vp, vp, vp, vp]),
         "ludwig_level_info": (C.c_int, [vp, C.POINTER(LevelInfo)]),
     }
     for name, (res, args) in sig.items():

@@ -48,6 +48,11 @@ class HipStepper:
     def field(self, level: int, name: str) -> np.ndarray:
         return self.dev[level].download(name)
 
+    def surface_stresses(self, level: int, mesh, params, search_radius: int = 5):
+        """per-triangle p, tau on the device (src/forces/surface.jl:138-266); reads the level's `vel` buffer like the reference"""
+        h = self.host[level]
+        return forces_mod.map_surface_stresses_device(mesh, self.dev[level], h.dx, h.tau, params, search_radius, "vel")
+
     def close(self):
         for d in self.dev:
             d.close()
@@ -103,6 +108,20 @@ class DistributedStepper:
                     lv.close()
 
 
+def _aerodynamics(st, grids, mesh, params, symmetric: bool, rho_f=None):
+    """compute_aerodynamics! (src/forces/surface.jl:592-600) on the finest level: stresses on the device when the stepper
+    offers it, else from downloaded fields; integration on the host either way."""
+    fin = len(grids) - 1
+    if hasattr(st, "surface_stresses"):
+        p, tx, ty, tz = st.surface_stresses(fin, mesh, params)
+        fr = forces_mod.integrate_surface_forces(mesh, p, tx, ty, tz, params, symmetric)
+        fr.maps = (p, tx, ty, tz)
+        return fr
+    if rho_f is None:
+        rho_f = st.field(fin, "rho")
+    return forces_mod.compute_aerodynamics(mesh, grids[fin], rho_f, st.field(fin, "vel"), params, symmetric)
+
+
 def flow_stats(rho: np.ndarray, obstacle: np.ndarray) -> float:
     """rho_min of compute_flow_stats (src/diagnostics.jl:56-94, CUDA branch): minimum over non-obstacle cells"""
     return float(rho[~obstacle].min())
@@ -147,9 +166,7 @@ def run_case(cfg: CaseConfig, stepper_factory: Callable = HipStepper, steps: Opt
                     rho_min = flow_stats(rho1, grids[0].obstacle)
                     cd = cl = cs = cmy = float("nan")
                     if cfg.forces_enabled:
-                        fin = len(grids) - 1
-                        rho_f = rho1 if fin == 0 else st.field(fin, "rho")
-                        fr = forces_mod.compute_aerodynamics(mesh, grids[fin], rho_f, st.field(fin, "vel"), params, cfg.symmetric_analysis)
+                        fr = _aerodynamics(st, grids, mesh, params, cfg.symmetric_analysis, rho1 if len(grids) == 1 else None)
                         cd, cl, cs, cmy = fr.Cd, fr.Cl, fr.Cs, fr.Cmy
                     rows.append(DiagRow(diag_step, float(u_curr), rho_min, cd, cl, cs, cmy))
                     now = _time.time()
@@ -181,8 +198,7 @@ def run_case(cfg: CaseConfig, stepper_factory: Callable = HipStepper, steps: Opt
                     for lvl in sorted({l for l, _ in mesh_arrays_needed}):
                         fields(lvl, "rho"); fields(lvl, vel_name)
                     if cfg.forces_enabled and (fr is None or out_step != (out_step // cfg.diag_freq) * cfg.diag_freq):
-                        fin = len(grids) - 1
-                        fr = forces_mod.compute_aerodynamics(mesh, grids[fin], fields(fin, "rho"), st.field(fin, "vel"), params, cfg.symmetric_analysis)
+                        fr = _aerodynamics(st, grids, mesh, params, cfg.symmetric_analysis)
                     if writing:
                         out_mod.export_merged_mesh(out_step, grids, fields, out_dir, cfg.output_fields)
                         if cfg.forces_enabled:

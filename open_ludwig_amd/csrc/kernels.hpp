@@ -848,6 +848,69 @@ __global__ void k_fill(float *a, int64_t n, float v)
     if (i < n) a[i] = v;
 }
 
+// ---- surface stresses, reference src/forces/surface.jl:32-76 (compute_stress_from_cell) and :138-266 (map_stresses_kernel!) ----
+struct SurfaceParams {
+    const float *rho, *vel;
+    const uint8_t *obstacle;
+    const int32_t *block_pointer;    // [gdx,gdy,gdz] 1-based, 0 = absent
+    int64_t sk;
+    int32_t gdx, gdy, gdz, n_tri, radius;
+    float dx, tau, off_x, off_y, off_z, pressure_scale, stress_scale;
+    const float *centers, *normals;  // [n_tri * 3]
+    float *p, *tx, *ty, *tz;         // [n_tri]
+};
+
+__global__ __launch_bounds__(128) void k_map_stresses(const SurfaceParams s)
+{
+    const int i = blockIdx.x * 128 + threadIdx.x;
+    if (i >= s.n_tri) return;
+    const float tx = s.centers[3 * i] + s.off_x, ty = s.centers[3 * i + 1] + s.off_y, tz = s.centers[3 * i + 2] + s.off_z;
+    const float nx = s.normals[3 * i], ny = s.normals[3 * i + 1], nz = s.normals[3 * i + 2];
+    const int g_x = (int)floorf(tx / s.dx) + 1, g_y = (int)floorf(ty / s.dx) + 1, g_z = (int)floorf(tz / s.dx) + 1;
+    float best_d = 1.0e10f, best_rho = 1.0f, ux = 0.0f, uy = 0.0f, uz = 0.0f, best_wd = 0.5f;
+    bool found = false;
+    for (int radius = 0; radius <= s.radius; ++radius) {
+        if (found && radius > 1) break;
+        for (int dz = -radius; dz <= radius; ++dz)
+            for (int dy = -radius; dy <= radius; ++dy)
+                for (int dx = -radius; dx <= radius; ++dx) {
+                    if (radius > 0 && !(abs(dx) == radius || abs(dy) == radius || abs(dz) == radius)) continue;   // the shell only
+                    const int cgx = g_x + dx, cgy = g_y + dy, cgz = g_z + dz;
+                    if (cgx < 1 || cgy < 1 || cgz < 1) continue;
+                    const int bx = (cgx - 1) / BS + 1, by = (cgy - 1) / BS + 1, bz = (cgz - 1) / BS + 1;
+                    if (bx > s.gdx || by > s.gdy || bz > s.gdz) continue;
+                    const int32_t b = s.block_pointer[(size_t)(bx - 1) + (size_t)s.gdx * ((size_t)(by - 1) + (size_t)s.gdy * (bz - 1))];
+                    if (b <= 0) continue;
+                    const int64_t c = (int64_t)((cgx - 1) % BS) + 8 * ((cgy - 1) % BS) + 64 * ((cgz - 1) % BS) + 512 * (int64_t)(b - 1);
+                    if (s.obstacle[c]) continue;
+                    const float ccx = ((float)cgx - 0.5f) * s.dx, ccy = ((float)cgy - 0.5f) * s.dx, ccz = ((float)cgz - 0.5f) * s.dx;
+                    const float ex = tx - ccx, ey = ty - ccy, ez = tz - ccz;
+                    const float d2 = ex * ex + ey * ey + ez * ez;
+                    if (d2 < best_d) {
+                        best_d = d2;
+                        best_rho = s.rho[c];
+                        ux = s.vel[c]; uy = s.vel[c + s.sk]; uz = s.vel[c + 2 * s.sk];
+                        best_wd = sqrtf(d2) / s.dx;
+                        found = true;
+                    }
+                }
+    }
+    float p = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    if (found) {
+        const float wall_dist = fmaxf(best_wd, 0.5f);
+        p = ((best_rho - 1.0f) / 3.0f) * s.pressure_scale;
+        const float udn = ux * nx + uy * ny + uz * nz;
+        const float utx = ux - udn * nx, uty = uy - udn * ny, utz = uz - udn * nz;
+        const float umag = sqrtf(utx * utx + uty * uty + utz * utz);
+        const float nu_lat = (s.tau - 0.5f) / 3.0f;
+        if (umag > 1.0e-10f && wall_dist > 0.01f) {
+            const float tmag = (best_rho * nu_lat * umag / wall_dist) * s.stress_scale;
+            sx = (utx / umag) * tmag; sy = (uty / umag) * tmag; sz = (utz / umag) * tmag;
+        }
+    }
+    s.p[i] = p; s.tx[i] = sx; s.ty[i] = sy; s.tz[i] = sz;
+}
+
 // ---- halo pack / unpack ----
 __global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst)
 {

@@ -886,6 +886,50 @@ int ludwig_sync(const LudwigLevel *L)
     return LUDWIG_OK;
 }
 
+int ludwig_map_surface_stresses(const LudwigLevel *L, int vel_field, int32_t n_tri, const float *centers, const float *normals,
+                                const LudwigSurfaceParams *sp, float *pressure, float *shear_x, float *shear_y, float *shear_z)
+{
+    if (!L || !sp || n_tri < 0 || (n_tri > 0 && (!centers || !normals || !pressure || !shear_x || !shear_y || !shear_z)))
+        return fail(LUDWIG_ERR_INVALID, "null argument");
+    if (vel_field != LUDWIG_VEL && vel_field != LUDWIG_VEL_TEMP) return fail(LUDWIG_ERR_INVALID, "vel_field must be LUDWIG_VEL or LUDWIG_VEL_TEMP");
+    if (n_tri == 0) return LUDWIG_OK;
+    if (L->n_blocks == 0 || L->h_block_pointer.size() != (size_t)L->gdx * L->gdy * L->gdz)
+        return fail(LUDWIG_ERR_STATE, "level has no blocks or was created without block_pointer");
+    if (!(sp->dx > 0.0f) || sp->search_radius < 0 || sp->search_radius > 16) return fail(LUDWIG_ERR_INVALID, "bad dx or search radius");
+    LW_HIP(hipSetDevice(L->device));
+    // scratch: [block_pointer | centers | normals | 4 outputs]; a diagnostics call every few hundred steps, so allocated per call
+    const size_t nptr = L->h_block_pointer.size(), n = (size_t)n_tri;
+    char *buf = nullptr;
+    const size_t bytes = nptr * 4 + n * 10 * 4;
+    LW_HIP(hipMalloc((void **)&buf, bytes));
+    int32_t *d_ptr = (int32_t *)buf;
+    float *d_c = (float *)(buf + nptr * 4), *d_n = d_c + 3 * n, *d_out = d_n + 3 * n;
+    hipError_t e = hipMemcpyAsync(d_ptr, L->h_block_pointer.data(), nptr * 4, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_c, centers, n * 12, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_n, normals, n * 12, hipMemcpyHostToDevice, L->stream);
+    if (e == hipSuccess) {
+        SurfaceParams s{};
+        s.rho = L->rho;
+        s.vel = L->vel[vel_field == LUDWIG_VEL ? 0 : 1];
+        s.obstacle = L->obstacle;
+        s.block_pointer = d_ptr;
+        s.sk = L->sk;
+        s.gdx = L->gdx; s.gdy = L->gdy; s.gdz = L->gdz; s.n_tri = n_tri; s.radius = sp->search_radius;
+        s.dx = sp->dx; s.tau = sp->tau; s.off_x = sp->offset_x; s.off_y = sp->offset_y; s.off_z = sp->offset_z;
+        s.pressure_scale = sp->pressure_scale; s.stress_scale = sp->stress_scale;
+        s.centers = d_c; s.normals = d_n;
+        s.p = d_out; s.tx = d_out + n; s.ty = d_out + 2 * n; s.tz = d_out + 3 * n;
+        hipLaunchKernelGGL(k_map_stresses, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, L->stream, s);
+        e = hipGetLastError();
+    }
+    float *outs[4] = {pressure, shear_x, shear_y, shear_z};
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipMemcpyAsync(outs[i], d_out + (size_t)i * n, n * 4, hipMemcpyDeviceToHost, L->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(LUDWIG_ERR_HIP, "surface stresses: %s", hipGetErrorString(e));
+    return LUDWIG_OK;
+}
+
 int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, float *dst_dev, void *hip_stream)
 {
     if (!L || (n > 0 && (!index_dev || !dst_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");

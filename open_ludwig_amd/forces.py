@@ -115,6 +115,23 @@ def map_surface_stresses(mesh, rho, vel, obstacle, block_pointer, dx, tau, param
     return p, tau_x.astype(np.float32), tau_y.astype(np.float32), tau_z.astype(np.float32)
 
 
+def map_surface_stresses_device(mesh, device_level, dx, tau, params, search_radius: int = 5, vel_name: str = "vel"):
+    """map_stresses_kernel! on the device that holds the level (ludwig_map_surface_stresses): same search, same Float32
+    expressions as map_surface_stresses above - the two are tested to agree bit for bit - without moving rho / vel to the host."""
+    import ctypes as C
+    from . import _lib
+    n = mesh.centers.shape[0]
+    centers = np.ascontiguousarray(mesh.centers, dtype=np.float32)
+    normals = np.ascontiguousarray(mesh.normals, dtype=np.float32)
+    off = params.mesh_offset.astype(np.float32)
+    scale = f32(params.rho_physical * params.velocity_scale * params.velocity_scale)
+    sp = _lib.SurfaceParams(float(f32(dx)), float(f32(tau)), float(off[0]), float(off[1]), float(off[2]), float(scale), float(scale), int(search_radius))
+    out = [np.empty(n, dtype=np.float32) for _ in range(4)]
+    _lib.check(_lib.load().ludwig_map_surface_stresses(device_level.handle, _lib.FIELD_NAMES[vel_name], n, centers.ctypes.data, normals.ctypes.data,
+                                                       C.byref(sp), *[a.ctypes.data for a in out]))
+    return tuple(out)
+
+
 def integrate_surface_forces(mesh, p, tau_x, tau_y, tau_z, params, symmetric: bool = False) -> ForceResult:
     off = params.mesh_offset.astype(np.float32)
     c = mesh.centers.astype(np.float32)

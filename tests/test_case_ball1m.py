@@ -258,3 +258,32 @@ def test_exported_cell_counts_match_reference_logs(ball_setup, ball_re10m_setup)
     for (cfg, setup), want in ((ball_setup, "1.42"), (ball_re10m_setup, "3.46")):
         sel = output.select_export_blocks([g.active_block_coords for g in setup[0]])
         assert "%.2f" % (len(sel) * 512 / 1e6) == want
+
+
+@pytest.mark.gpu
+def test_device_stress_mapping_equals_host_mapping(gpu, ball_setup):
+    """ludwig_map_surface_stresses (one thread per triangle on the device) against the numpy restatement of
+    map_stresses_kernel! on the downloaded fields of the same state: all four per-triangle arrays bit-identical, hence the
+    same Cd / Cl; also with a search radius too small to reach fluid for some triangles, and on the other velocity buffer."""
+    from open_ludwig_amd import forces
+    cfg, (grids, mesh, params, rep) = ball_setup
+    sp = pp.solver_params(cfg, params)
+    st = case.HipStepper(grids)
+    st.batch(1, 120, np.float32(0.02), sp)
+    fin = len(grids) - 1
+    rho, vel, vel_t = st.field(fin, "rho"), st.field(fin, "vel"), st.field(fin, "vel_temp")
+    for radius, vname, v in ((5, "vel", vel), (0, "vel", vel), (1, "vel", vel), (2, "vel_temp", vel_t)):
+        want = forces.map_surface_stresses(mesh, rho, v, grids[fin].obstacle, grids[fin].block_pointer, grids[fin].dx, grids[fin].tau, params, radius)
+        got = forces.map_surface_stresses_device(mesh, st.dev[fin], grids[fin].dx, grids[fin].tau, params, radius, vname)
+        for name, a, b in zip(("p", "tau_x", "tau_y", "tau_z"), got, want):
+            assert np.array_equal(a, b), (radius, vname, name, int((a != b).sum()))
+        if radius == 5:
+            assert np.count_nonzero(got[0]) == mesh.centers.shape[0] and np.abs(got[1]).max() > 0
+        if radius == 0:
+            assert not got[0].any(), "every triangle centre lies in a voxelised (solid) cell: radius 0 maps nothing"
+        if radius == 1:
+            assert 0 < np.count_nonzero(got[0] == 0) < mesh.centers.shape[0], "radius 1 reaches fluid for some triangles only"
+    fr_dev = case._aerodynamics(st, grids, mesh, params, False)
+    fr_host = forces.compute_aerodynamics(mesh, grids[fin], rho, vel, params, False)
+    assert fr_dev.Cd == fr_host.Cd and fr_dev.Cl == fr_host.Cl and fr_dev.Fx_viscous == fr_host.Fx_viscous
+    st.close()
