@@ -24,6 +24,7 @@ struct LevelHost               # LudwigLevelHost
     bouzidi_q_map::Ptr{UInt16}; bouzidi_cell_block::Ptr{Int32}
     bouzidi_cell_x::Ptr{Int8}; bouzidi_cell_y::Ptr{Int8}; bouzidi_cell_z::Ptr{Int8}
     comm_boundary::Ptr{UInt8}
+    store_post_collision_everywhere::Int32   # 0: f_post_collision only where the Bouzidi kernel reads it
 end
 
 struct StepFlags               # LudwigStepFlags
@@ -57,7 +58,7 @@ function adapt_level(level, device::Integer = 0)
                       level.bouzidi_enabled ? pointer(level.bouzidi_cell_x) : Ptr{Int8}(C_NULL),
                       level.bouzidi_enabled ? pointer(level.bouzidi_cell_y) : Ptr{Int8}(C_NULL),
                       level.bouzidi_enabled ? pointer(level.bouzidi_cell_z) : Ptr{Int8}(C_NULL),
-                      Ptr{UInt8}(C_NULL))
+                      Ptr{UInt8}(C_NULL), Int32(0))
         out = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:ludwig_level_create, LIB), Cint, (Ref{LevelHost}, Cint, Ref{Ptr{Cvoid}}), h, device, out))
         d = DeviceLevel(out[], level.level_id, level.tau, n, length(level.f_old) > 27, level.bouzidi_enabled, level.n_boundary_cells)
