@@ -287,3 +287,38 @@ def test_device_stress_mapping_equals_host_mapping(gpu, ball_setup):
     fr_host = forces.compute_aerodynamics(mesh, grids[fin], rho, vel, params, False)
     assert fr_dev.Cd == fr_host.Cd and fr_dev.Cl == fr_host.Cl and fr_dev.Fx_viscous == fr_host.Fx_viscous
     st.close()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_on_ball1m_re10m(gpu, ball_re10m_setup):
+    """The 4-level case (tau_fine 0.500001, sponge reaching level 2, 28 400 Bouzidi cells, wall model): 48 coarse steps
+    (980 M cell updates) on HIP and on the CPU oracle; every level's rho / vel within the north_star's 1e-5 relative (the
+    only non-identical arithmetic is the wall model's pow / log), Cd within 1e-5."""
+    import copy
+    from _steppers import OracleStepper
+    from oracle import oracle
+    oracle.set_num_threads(16)
+    cfg, _ = ball_re10m_setup
+    cfg = copy.copy(cfg)
+    cfg.diag_freq, cfg.output_freq, steps = 48, 10 ** 9, 48
+    stl = os.path.join(G, "ball1m.stl")
+    setup_h, setup_o = pp.setup_multilevel_domain(cfg, stl), pp.setup_multilevel_domain(cfg, stl)
+    keep = {}
+
+    def hip_factory(grids):
+        keep["st"] = case.HipStepper(grids)
+        keep["st"].close = lambda: None              # keep the device levels for the field comparison below
+        return keep["st"]
+
+    hip, _, _ = case.run_case(cfg, hip_factory, steps=steps, setup=setup_h)
+    ora, _, _ = case.run_case(cfg, OracleStepper, steps=steps, setup=setup_o)
+    assert len(hip) == len(ora) == 1
+    assert abs(hip[0].cd - ora[0].cd) <= 1e-5 * abs(ora[0].cd) and abs(hip[0].rho_min - ora[0].rho_min) <= 1e-6
+    for i, g in enumerate(setup_o[0]):
+        fn, vn = oracle.newest_buffers(i, steps)
+        for name in ("rho", vn, fn):
+            a, b = keep["st"].dev[i].download(name), getattr(g, name)
+            err = np.abs(a.astype(np.float64) - b).max() / np.abs(b).max()
+            assert err <= 1e-5, (i + 1, name, err)
+    for d in keep["st"].dev:
+        d.close()
