@@ -70,10 +70,17 @@ def main():
         import json
         from open_ludwig_amd import case, preprocess as pp
         G = os.path.join(ROOT, "tests", "golden")
-        cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"),
-                                         {"basic": {"surface_resolution": 25, "flow": {"velocity": 4.0}, "simulation": {"steps": 6000, "output_freq": 1000}}})
+        if nbx == 1:      # the synthetic half wing (symmetry plane, inlet turbulence, wall model): tests/_wing.py
+            import _wing
+            stl = os.path.join(outdir, f"wing_rank{rank}.stl")
+            _wing.write_binary_stl(stl, _wing.half_wing_triangles())
+            cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"), _wing.TEST_OVERRIDES)
+        else:
+            stl = os.path.join(G, "ball1m.stl")
+            cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"),
+                                             {"basic": {"surface_resolution": 25, "flow": {"velocity": 4.0}, "simulation": {"steps": 6000, "output_freq": 1000}}})
         cfg.diag_freq = 20
-        setup = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
+        setup = pp.setup_multilevel_domain(cfg, stl)
         holder = {}
 
         def factory(grids):
@@ -84,7 +91,7 @@ def main():
         st = holder["st"]
         stats = [[v.n_owned, v.level.n_blocks, st.runner.ex[i].plan.bytes_per_step()] for i, v in enumerate(st.runner.views)]
         if rank == 0:
-            json.dump({"rows": [[r.step, r.u_lat, r.rho_min, r.cd, r.cl] for r in rows]}, open(os.path.join(outdir, "rows.json"), "w"))
+            json.dump({"rows": [[r.step, r.u_lat, r.rho_min, r.cd, r.cl, r.cs, r.cmy] for r in rows]}, open(os.path.join(outdir, "rows.json"), "w"))
         json.dump(stats, open(os.path.join(outdir, f"stats{rank}.json"), "w"))
         dist.barrier()
         dist.destroy_process_group()

@@ -134,7 +134,7 @@ def test_ball1m_on_two_ranks_equals_single_device(gpu, ball_setup, tmp_path):
     assert len(rows) == len(single) == 3
     for got, want in zip(rows, single):
         assert got[0] == want.step
-        assert got[1:] == [want.u_lat, want.rho_min, want.cd, want.cl], (got, want)
+        assert got[1:5] == [want.u_lat, want.rho_min, want.cd, want.cl], (got, want)
     stats = [json.load(open(os.path.join(tmp_path, f"stats{r}.json"))) for r in range(2)]
     for lvl in range(3):
         assert sum(s[lvl][0] for s in stats) == setup[0][lvl].n_blocks
