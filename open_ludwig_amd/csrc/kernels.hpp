@@ -557,12 +557,20 @@ __device__ __forceinline__ float dpp_from_upper_lane(float v)   // lane i <- lan
 // cx=-1 populations their x=0 column in slots 9..17 (k = (cx+1) + 3 j, j = 0..8)
 __host__ __device__ constexpr int XSLOT(int k) { return CX(k) == 1 ? k / 3 : 9 + k / 3; }
 
+// work item of the x-run kernel: (block << 3) | z in the low bits, plus which of its lateral faces are served by the
+// neighbouring wave of the workgroup (LDS) rather than by a strided column read from global memory
+constexpr int ITEM_LINK_W = 1 << 30;   // wave - 1 of this workgroup holds the -x neighbour block, same plane
+constexpr int ITEM_LINK_E = 1 << 29;   // wave + 1 holds the +x neighbour block, same plane
+constexpr int ITEM_ID_MASK = (1 << 29) - 1;
+
 template <int NW, bool POST, bool WALL>
 __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams p)
 {
     __shared__ float xch[NW][24][8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = p.items[blockIdx.x * NW + wave];
+    const int raw = p.items[blockIdx.x * NW + wave];
+    const bool active = raw >= 0;                             // -1 = idle wave (padding); it still meets the barrier
+    const int item = active ? (raw & ITEM_ID_MASK) : 0;
     const int b = item >> 3;
     const int z = item & 7;
     const int lane = threadIdx.x & 63;
@@ -573,11 +581,13 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     const int flags = meta[NBR_FLAGS];
     const NeighbourIds nbr = load_neighbour_ids(meta, z);
     const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
-    const bool first = wave == 0, last = wave == NW - 1;      // wave-uniform
-
-    // ---- aligned loads: value of population k at (x, y - cy, z - cz) ----
+    // wave-uniform: a run may be shorter than the workgroup (several short runs, or single blocks, share one)
+    const bool first = !active || (raw & ITEM_LINK_W) == 0, last = !active || (raw & ITEM_LINK_E) == 0;
     float fs[Q];
-    float halo[Q];                                            // outer-face column (first / last wave only)
+    float halo[Q];                                            // outer-face column (run ends only)
+    float uc[3], uT[3], uB[3], uy_edge[3], ux_edge_lo[3], ux_edge_hi[3];
+    if (active) {
+    // ---- aligned loads: value of population k at (x, y - cy, z - cz) ----
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
 #ifdef LW_DIAG_NO_YSHIFT   // timing-only
@@ -609,7 +619,6 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         }
     });
     // previous-step velocity: centre plane, planes z+-1 (aligned), y-face rows and outer x-face columns (masked)
-    float uc[3], uT[3], uB[3], uy_edge[3], ux_edge_lo[3], ux_edge_hi[3];
     {
         const int bT = z == 7 ? nbr.id[2][4] : b, bB = z == 0 ? nbr.id[0][4] : b;
         const uint32_t xy = (uint32_t)((l.x + 8 * l.y) * 4);
@@ -656,7 +665,9 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         if (l.x7) xch[wave][18 + c][l.y] = uc[c];
         if (l.x0) xch[wave][21 + c][l.y] = uc[c];
     }
+    }   // if (active)
     __syncthreads();
+    if (!active) return;
     const int wlo = first ? 0 : wave - 1, whi = last ? NW - 1 : wave + 1;
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;

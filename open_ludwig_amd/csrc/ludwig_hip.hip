@@ -71,6 +71,7 @@ struct LudwigLevel {
     int32_t *items[N_PARTS][N_CLASSES] = {};
     int64_t n_items[N_PARTS][N_CLASSES] = {};
     int n_fast_blocks = 0;
+    int64_t n_linked_items[N_PARTS] = {};   // class-2 waves that exchange a face column with a neighbouring wave
     int64_t device_bytes = 0;
     // coarse -> fine interface pass (levels >= 2): links per part, built lazily for the global box of the first step
     int n_iface_blocks = 0;
@@ -212,24 +213,42 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
         }
     }
     const bool use_xrun = getenv("LUDWIG_NO_XRUN") == nullptr;
-    for (int64_t g = 0; g < n; g += XRUN) {
-        const int64_t m = std::min<int64_t>(XRUN, n - g);
-        bool run = use_xrun && m == XRUN;
-        for (int64_t w = 0; run && w < m; ++w) {
-            const int32_t it = items[g + w];
-            if (it < 0 || !is_fast(it >> 3) || (it & 7) != (items[g] & 7)) run = false;
-            else if (w > 0 && L->h_meta[(size_t)(items[g + w - 1] >> 3) * NBR_STRIDE + DIR(1, 0, 0)] != (it >> 3)) run = false;
+    if (!use_xrun) {                                    // diagnostics: everything wave by wave
+        for (int64_t i = 0; i < n; ++i) {
+            if (items[i] < 0) cls[0].push_back(-1);
+            else cls[is_fast(items[i] >> 3) ? 0 : 1].push_back(items[i]);
         }
-        if (run) {
-            for (int64_t w = 0; w < m; ++w) cls[2].push_back(items[g + w]);
-            for (int64_t w = 0; w < m; ++w) cls[0].push_back(-1);   // keep class 0's slot -> XCD alignment
-        } else {
+    } else {
+        // All-neighbour blocks -> x-run kernel (class 2), XRUN waves per workgroup; a wave is LINKED to the next one when
+        // that one holds its +x neighbour block at the same plane (then the face column travels through LDS). Workgroups
+        // of the caller's order that hold only such blocks keep their composition (and with it their XCD slot); loose
+        // all-neighbour items of mixed workgroups are re-packed at the end. Blocks with a missing neighbour -> class 1.
+        std::vector<int32_t> loose;
+        for (int64_t g = 0; g < n; g += XRUN) {
+            const int64_t m = std::min<int64_t>(XRUN, n - g);
+            bool pure = m == XRUN;
+            for (int64_t w = 0; w < m; ++w)
+                if (items[g + w] >= 0 && !is_fast(items[g + w] >> 3)) pure = false;
             for (int64_t w = 0; w < m; ++w) {
                 const int32_t it = items[g + w];
-                if (it < 0) cls[0].push_back(-1);
-                else cls[is_fast(it >> 3) ? 0 : 1].push_back(it);
+                if (pure) cls[2].push_back(it);
+                else if (it >= 0) (is_fast(it >> 3) ? loose : cls[1]).push_back(it);
             }
         }
+        cls[2].insert(cls[2].end(), loose.begin(), loose.end());
+        while (cls[2].size() % XRUN) cls[2].push_back(-1);
+        for (size_t g = 0; g < cls[2].size(); g += XRUN)
+            for (int w = 0; w + 1 < XRUN; ++w) {
+                const int32_t a = cls[2][g + w], c = cls[2][g + w + 1];
+                if (a < 0 || c < 0 || (a & 7) != (c & 7)) continue;
+                const int ba = (a & ITEM_ID_MASK) >> 3, bc = c >> 3;     // `a` may already carry its west link
+                if (ba == bc || L->h_meta[(size_t)ba * NBR_STRIDE + DIR(1, 0, 0)] != bc) continue;
+                cls[2][g + w] |= ITEM_LINK_E;
+                cls[2][g + w + 1] |= ITEM_LINK_W;
+            }
+        L->n_linked_items[part] = 0;
+        for (int32_t it : cls[2])
+            if (it >= 0 && (it & (ITEM_LINK_E | ITEM_LINK_W))) ++L->n_linked_items[part];
     }
     for (int c = 0; c < N_CLASSES; ++c) {
         bool any = false;
@@ -271,9 +290,9 @@ int default_items(LudwigLevel *L, int part)
         return a.bx < c.bx;
     });
     auto fast = [&](int b) { return (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0; };
-    struct Group { int32_t by, bx0, bz; int32_t b[XRUN_MAX]; };
-    std::vector<Group> runs;
-    std::vector<Blk> singles;
+    struct Group { int32_t by, bx0, bz; int32_t n; int32_t b[XRUN_MAX]; };
+    std::vector<Group> runs, shorts;      // full runs; leftover chains of 1 .. XRUN-1 all-neighbour blocks
+    std::vector<Blk> singles;             // blocks with a missing neighbour
     size_t i = 0;
     while (i < blks.size()) {
         // maximal chain of x-consecutive fast blocks starting at i (same by,bz row)
@@ -285,15 +304,26 @@ int default_items(LudwigLevel *L, int part)
         }
         size_t k = i;
         for (; k + XRUN <= j + 1; k += XRUN) {
-            Group g{blks[k].by, blks[k].bx, blks[k].bz, {}};
+            Group g{blks[k].by, blks[k].bx, blks[k].bz, XRUN, {}};
             for (int w = 0; w < XRUN; ++w) g.b[w] = blks[k + w].b;
             runs.push_back(g);
         }
-        for (; k <= j; ++k) singles.push_back(blks[k]);
+        if (k <= j && fast(blks[k].b)) {
+            Group g{blks[k].by, blks[k].bx, blks[k].bz, (int32_t)(j + 1 - k), {}};
+            for (size_t w = k; w <= j; ++w) g.b[w - k] = blks[w].b;
+            shorts.push_back(g);
+        } else {
+            for (; k <= j; ++k) singles.push_back(blks[k]);
+        }
         i = j + 1;
     }
     // sweep: y fastest (y-neighbour groups re-read each other's face rows: next workgroup on the same XCD), then x, then z
     std::sort(runs.begin(), runs.end(), [](const Group &a, const Group &c) {
+        if (a.bz != c.bz) return a.bz < c.bz;
+        if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
+        return a.by < c.by;
+    });
+    std::sort(shorts.begin(), shorts.end(), [](const Group &a, const Group &c) {
         if (a.bz != c.bz) return a.bz < c.bz;
         if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
         return a.by < c.by;
@@ -311,6 +341,21 @@ int default_items(LudwigLevel *L, int part)
             const int z = ((x - g.bz) % 8 + 8) % 8;
             for (int w = 0; w < XRUN; ++w) seq.push_back((g.b[w] << 3) | z);
         }
+    // leftover chains: whole chains packed into workgroups of XRUN waves (never split), same slot rule
+    for (size_t s0 = 0; s0 < shorts.size();) {
+        int32_t wg[XRUN_MAX];
+        int used = 0;
+        const int bz0 = shorts[s0].bz;
+        while (s0 < shorts.size() && used + shorts[s0].n <= XRUN) {
+            for (int w = 0; w < shorts[s0].n; ++w) wg[used++] = shorts[s0].b[w];
+            ++s0;
+        }
+        for (int x = 0; x < 8; ++x) {
+            const int z = ((x - bz0) % 8 + 8) % 8;
+            for (int w = 0; w < XRUN; ++w) seq.push_back(w < used ? (wg[w] << 3) | z : -1);
+        }
+    }
+    while (seq.size() % (8 * XRUN)) seq.push_back(-1);     // the wave-by-wave part below is laid out in workgroups of 4
     for (size_t s0 = 0; s0 < singles.size(); s0 += 4)
         for (int x = 0; x < 8; ++x) {
             const int z = ((x - singles[s0].bz) % 8 + 8) % 8;
@@ -970,7 +1015,7 @@ int ludwig_level_info(const LudwigLevel *L, LudwigLevelInfo *info)
     info->n_boundary_cells = L->n_bc;
     info->has_temporal_storage = L->has_temporal;
     info->has_post_collision = L->has_post;
-    info->n_xrun_blocks = (int32_t)(L->n_items[LUDWIG_PART_ALL][2] / 8);   // 8 planes per block
+    info->n_xrun_blocks = (int32_t)(L->n_linked_items[LUDWIG_PART_ALL] / 8);   // 8 planes per block
     info->device_bytes = L->device_bytes;
     return LUDWIG_OK;
 }

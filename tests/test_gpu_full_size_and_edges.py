@@ -22,7 +22,7 @@ def test_256_cubed_conservation_and_order_independence(gpu):
     mom0 = [(g.rho.astype(np.float64) * g.vel[..., c]).sum() for c in range(3)]
     a = adapt(g, 0)
     b = adapt(g, 0)
-    b.set_order(order_mod.build("block_planes", coords))           # per-wave kernel, block order
+    b.set_order(order_mod.build("block_planes", coords))           # block order: no wave has its x neighbour next to it
     assert a.info().n_xrun_blocks == g.n_blocks and b.info().n_xrun_blocks == 0
     del grids
     steps = 6
