@@ -446,6 +446,52 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     });
 }
 
+// Lanes whose source block is missing: the domain-edge chain of reference src/physics_kernels.jl:88-140 (1-based global
+// coords) decides what replaces the pulled value - inlet / outlet equilibrium, mirror of the own cell, the coarse->fine
+// interface value, or the weight. Runs after all loads were issued (the lane read a valid dummy address meanwhile).
+__device__ __forceinline__ void patch_missing_sources(const SCParams &p, const int32_t *__restrict__ meta, const NeighbourIds &nbr,
+                                                      const LanePos &l, const int b, const int z, const uint32_t own_bytes, float (&fs)[Q])
+{
+    const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
+    const float *iface_own = p.is_level_1 == 0 ? p.f_iface + (size_t)meta[NBR_GBI] * CELLS + ((own_bytes >> 2) - (size_t)b * CELLS) : nullptr;
+    static_for<0, Q>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
+        if constexpr (k != 13) {
+            if (source_block<k>(nbr, l) < 0) {
+                const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
+                const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
+                const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
+                const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
+                float val;
+                if (is_inlet) {
+                    const float noise = p.inlet_turbulence > 0.0f
+                                            ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
+                                            : 0.0f;
+                    const float u_inst = p.u_inlet + noise;
+                    const float cu_in = (float)cx * u_inst;
+                    val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
+                } else if (is_outlet) {
+                    const float cu_out = (float)cx * p.u_inlet;
+                    val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
+                } else if (is_y_min && p.is_symmetric == 1) {
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                } else if (is_y_min || is_y_max) {
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                } else if (is_z_min || is_z_max) {
+                    val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
+                } else if (p.is_level_1 == 0) {
+                    // value computed by k_interface_links for exactly this (cell, k) link (same function, same inputs)
+                    val = iface_own[(size_t)k * p.n_iface_blocks * CELLS];
+                } else {
+                    val = WEIGHT(k);
+                }
+                fs[k] = val;
+            }
+        }
+    });
+}
+
 // GENERAL: blocks with a missing neighbour (domain edge / refinement interface); POST: also store f_post_collision
 // (level has Bouzidi cells); WALL: wall model active.
 #ifndef LW_WAVES_PER_EU
@@ -482,47 +528,7 @@ __global__ __launch_bounds__(256) LW_WAVES_ATTR void k_stream_collide(const SCPa
         const uint32_t off = (uint32_t)safe * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
         fs[k] = ld_f32(p.f_in + p.sk * k, off);
     });
-    if constexpr (GENERAL) {
-        // domain-edge chain, reference src/physics_kernels.jl:88-140 (1-based global coords)
-        const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
-        const float *iface_own = p.is_level_1 == 0 ? p.f_iface + (size_t)meta[NBR_GBI] * CELLS + ((own_bytes >> 2) - (size_t)b * CELLS) : nullptr;
-        static_for<0, Q>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
-            if constexpr (k != 13) {
-                if (source_block<k>(nbr, l) < 0) {
-                    const int src_gx = gx - cx, src_gy = gy - cy, src_gz = gz - cz;
-                    const bool is_inlet = src_gx < 1, is_outlet = src_gx > p.nx_g;
-                    const bool is_y_min = src_gy < 1, is_y_max = src_gy > p.ny_g;
-                    const bool is_z_min = src_gz < 1, is_z_max = src_gz > p.nz_g;
-                    float val;
-                    if (is_inlet) {
-                        const float noise = p.inlet_turbulence > 0.0f
-                                                ? gradient_noise(gy, gz, p.seed, 1234) * p.inlet_turbulence * p.u_inlet
-                                                : 0.0f;
-                        const float u_inst = p.u_inlet + noise;
-                        const float cu_in = (float)cx * u_inst;
-                        val = WEIGHT(k) * (1.0f + 3.0f * cu_in + 4.5f * cu_in * cu_in - 1.5f * u_inst * u_inst);
-                    } else if (is_outlet) {
-                        const float cu_out = (float)cx * p.u_inlet;
-                        val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
-                    } else if (is_y_min && p.is_symmetric == 1) {
-                        val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
-                    } else if (is_y_min || is_y_max) {
-                        val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
-                    } else if (is_z_min || is_z_max) {
-                        val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
-                    } else if (p.is_level_1 == 0) {
-                        // value computed by k_interface_links for exactly this (cell, k) link (same function, same inputs)
-                        val = iface_own[(size_t)k * p.n_iface_blocks * CELLS];
-                    } else {
-                        val = WEIGHT(k);
-                    }
-                    fs[k] = val;
-                }
-            }
-        });
-    }
+    if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, b, z, own_bytes, fs);
     // previous-step velocity of the 6 face neighbours (WALE stencil) - issued with the pulls so that all loads of the
     // wave are in flight together; reference src/physics_utils.jl:72-83
     float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
@@ -563,7 +569,7 @@ constexpr int ITEM_LINK_W = 1 << 30;   // wave - 1 of this workgroup holds the -
 constexpr int ITEM_LINK_E = 1 << 29;   // wave + 1 holds the +x neighbour block, same plane
 constexpr int ITEM_ID_MASK = (1 << 29) - 1;
 
-template <int NW, bool POST, bool WALL>
+template <int NW, bool GENERAL, bool POST, bool WALL>
 __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams p)
 {
     __shared__ float xch[NW][24][8];
@@ -597,7 +603,8 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
 #endif
         const bool yo = cy == 1 ? l.y0 : (cy == -1 ? l.y7 : false);
         const int c00 = nbr.id[g][4], cY = nbr.id[g][4 - 3 * cy];
-        const int sel = cy != 0 ? (yo ? cY : c00) : c00;
+        int sel = cy != 0 ? (yo ? cY : c00) : c00;
+        if constexpr (GENERAL) sel = sel >= 0 ? sel : b;      // missing block: in-bounds dummy, patched after the exchange
         const uint32_t rowz = (uint32_t)((8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(nbr.zs[g] * 256);
         const float *fk = p.f_in + p.sk * k;
         // populations with cy = 0: the two lines of this plane are read by this wave only (the x neighbours get their
@@ -612,7 +619,8 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
             if (cx == 1 ? first : last) {                     // the run's outer face: strided column of the x / xy neighbour
 #endif
                 const int cX = nbr.id[g][4 - cx], cXY = nbr.id[g][4 - cx - 3 * cy];
-                const int selx = cy != 0 ? (yo ? cXY : cX) : cX;
+                int selx = cy != 0 ? (yo ? cXY : cX) : cX;
+                if constexpr (GENERAL) selx = selx >= 0 ? selx : b;
                 if (cx == 1 ? l.x0 : l.x7)
                     halo[k] = ld_f32(fk, (uint32_t)selx * (CELLS * 4) + rowz + (uint32_t)((cx == 1 ? 7 : 0) * 4));
             }
@@ -622,13 +630,20 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     {
         const int bT = z == 7 ? nbr.id[2][4] : b, bB = z == 0 ? nbr.id[0][4] : b;
         const uint32_t xy = (uint32_t)((l.x + 8 * l.y) * 4);
-        const uint32_t offT = (uint32_t)bT * (CELLS * 4) + xy + (uint32_t)(((z + 1) & 7) * 256);
-        const uint32_t offB = (uint32_t)bB * (CELLS * 4) + xy + (uint32_t)(((z - 1) & 7) * 256);
+        uint32_t offT = (uint32_t)bT * (CELLS * 4) + xy + (uint32_t)(((z + 1) & 7) * 256);
+        uint32_t offB = (uint32_t)bB * (CELLS * 4) + xy + (uint32_t)(((z - 1) & 7) * 256);
         // lanes y==0 fetch row 7 of the -y neighbour, lanes y==7 row 0 of the +y neighbour (one masked load per component)
         const int by_ = l.y0 ? nbr.id[1][4 - 3] : nbr.id[1][4 + 3];
-        const uint32_t offY = (uint32_t)by_ * (CELLS * 4) + (uint32_t)((l.x + 8 * (l.y0 ? 7 : 0) + 64 * z) * 4);
-        const uint32_t offXlo = (uint32_t)nbr.id[1][4 - 1] * (CELLS * 4) + (uint32_t)((7 + 8 * l.y + 64 * z) * 4);
-        const uint32_t offXhi = (uint32_t)nbr.id[1][4 + 1] * (CELLS * 4) + (uint32_t)((0 + 8 * l.y + 64 * z) * 4);
+        uint32_t offY = (uint32_t)by_ * (CELLS * 4) + (uint32_t)((l.x + 8 * (l.y0 ? 7 : 0) + 64 * z) * 4);
+        uint32_t offXlo = (uint32_t)nbr.id[1][4 - 1] * (CELLS * 4) + (uint32_t)((7 + 8 * l.y + 64 * z) * 4);
+        uint32_t offXhi = (uint32_t)nbr.id[1][4 + 1] * (CELLS * 4) + (uint32_t)((0 + 8 * l.y + 64 * z) * 4);
+        if constexpr (GENERAL) {      // missing neighbour block -> the cell's own velocity (reference src/physics_utils.jl:45-70)
+            if (bT < 0) offT = own_bytes;
+            if (bB < 0) offB = own_bytes;
+            if (by_ < 0) offY = own_bytes;
+            if (nbr.id[1][4 - 1] < 0) offXlo = own_bytes;
+            if (nbr.id[1][4 + 1] < 0) offXhi = own_bytes;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float *vc = p.vel_in + p.sk * c;
@@ -697,6 +712,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         uN[c] = l.y7 ? uy_edge[c] : n_in;
         uS[c] = l.y0 ? uy_edge[c] : s_in;
     }
+    if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, b, z, own_bytes, fs);
     finish_cell<POST, WALL>(p, flags, own_bytes, fs, uE[0], uE[1], uE[2], uW[0], uW[1], uW[2], uN[0], uN[1], uN[2], uS[0], uS[1], uS[2],
                             uT[0], uT[1], uT[2], uB[0], uB[1], uB[2]);
 }

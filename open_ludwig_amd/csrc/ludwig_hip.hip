@@ -71,6 +71,7 @@ struct LudwigLevel {
     int32_t *items[N_PARTS][N_CLASSES] = {};
     int64_t n_items[N_PARTS][N_CLASSES] = {};
     int n_fast_blocks = 0;
+    bool general_in_runs[N_PARTS] = {};     // class-1 items are in x-run format (link bits, XRUN waves per workgroup)
     int64_t n_linked_items[N_PARTS] = {};   // class-2 waves that exchange a face column with a neighbouring wave
     int64_t device_bytes = 0;
     // coarse -> fine interface pass (levels >= 2): links per part, built lazily for the global box of the first step
@@ -198,11 +199,21 @@ bool block_in_part(const LudwigLevel *L, int b, int part)
     return part == LUDWIG_PART_BOUNDARY ? bnd : !bnd;
 }
 
+// LUDWIG_MERGE_CLASSES: 1 = always one launch per pass, 0 = never, unset = levels below MERGE_BELOW_BLOCKS owned blocks
+constexpr int MERGE_BELOW_BLOCKS = 8192;      // 4.2 M cells: above that a pass is > 0.2 ms and the extra launch is noise
+bool merge_classes(const LudwigLevel *L, const std::vector<int32_t> &general, const std::vector<int32_t> &fast)
+{
+    if (general.empty() || fast.empty()) return false;
+    const char *e = getenv("LUDWIG_MERGE_CLASSES");
+    if (e) return atoi(e) != 0;
+    return L->n_owned < MERGE_BELOW_BLOCKS;
+}
+
 int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
 {
-    // one item per wave: (block << 3) | z, or -1 = idle wave. 4 consecutive items form one 256-thread workgroup.
-    // A workgroup whose 4 items are the same plane of 4 x-consecutive all-neighbour blocks goes to the x-run kernel
-    // (class 2); everything else is stepped wave by wave (class 0 / 1).
+    // one item per wave: (block << 3) | z, or -1 = idle wave. XRUN consecutive items form one workgroup.
+    // class 2: all-neighbour blocks, class 1: blocks with a missing neighbour - both through the x-run kernel;
+    // class 0 (wave-by-wave kernel) only with LUDWIG_NO_XRUN (diagnostics).
     std::vector<int32_t> cls[N_CLASSES];
     auto is_fast = [&](int b) { return (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0; };
     for (int64_t i = 0; i < n; ++i) {
@@ -213,6 +224,7 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
         }
     }
     const bool use_xrun = getenv("LUDWIG_NO_XRUN") == nullptr;
+    L->general_in_runs[part] = use_xrun;
     if (!use_xrun) {                                    // diagnostics: everything wave by wave
         for (int64_t i = 0; i < n; ++i) {
             if (items[i] < 0) cls[0].push_back(-1);
@@ -223,38 +235,49 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
         // that one holds its +x neighbour block at the same plane (then the face column travels through LDS). Workgroups
         // of the caller's order that hold only such blocks keep their composition (and with it their XCD slot); loose
         // all-neighbour items of mixed workgroups are re-packed at the end. Blocks with a missing neighbour -> class 1.
-        std::vector<int32_t> loose;
+        std::vector<int32_t> loose[2];                     // [0] all-neighbour, [1] general items of mixed workgroups
         for (int64_t g = 0; g < n; g += XRUN) {
             const int64_t m = std::min<int64_t>(XRUN, n - g);
-            bool pure = m == XRUN;
+            int n_fast = 0, n_gen = 0;
             for (int64_t w = 0; w < m; ++w)
-                if (items[g + w] >= 0 && !is_fast(items[g + w] >> 3)) pure = false;
+                if (items[g + w] >= 0) (is_fast(items[g + w] >> 3) ? n_fast : n_gen)++;
+            const bool pure = m == XRUN && (n_fast == 0 || n_gen == 0);
             for (int64_t w = 0; w < m; ++w) {
                 const int32_t it = items[g + w];
-                if (pure) cls[2].push_back(it);
-                else if (it >= 0) (is_fast(it >> 3) ? loose : cls[1]).push_back(it);
+                if (pure) { if (n_fast + n_gen > 0) cls[n_gen > 0 ? 1 : 2].push_back(it); }
+                else if (it >= 0) loose[is_fast(it >> 3) ? 0 : 1].push_back(it);
             }
         }
-        cls[2].insert(cls[2].end(), loose.begin(), loose.end());
-        while (cls[2].size() % XRUN) cls[2].push_back(-1);
-        for (size_t g = 0; g < cls[2].size(); g += XRUN)
-            for (int w = 0; w + 1 < XRUN; ++w) {
-                const int32_t a = cls[2][g + w], c = cls[2][g + w + 1];
-                if (a < 0 || c < 0 || (a & 7) != (c & 7)) continue;
-                const int ba = (a & ITEM_ID_MASK) >> 3, bc = c >> 3;     // `a` may already carry its west link
-                if (ba == bc || L->h_meta[(size_t)ba * NBR_STRIDE + DIR(1, 0, 0)] != bc) continue;
-                cls[2][g + w] |= ITEM_LINK_E;
-                cls[2][g + w + 1] |= ITEM_LINK_W;
-            }
+        for (int c = 1; c <= 2; ++c) {
+            const std::vector<int32_t> &lo = loose[c == 2 ? 0 : 1];
+            cls[c].insert(cls[c].end(), lo.begin(), lo.end());
+            while (cls[c].size() % XRUN) cls[c].push_back(-1);
+            for (size_t g = 0; g < cls[c].size(); g += XRUN)
+                for (int w = 0; w + 1 < XRUN; ++w) {
+                    const int32_t a = cls[c][g + w], d = cls[c][g + w + 1];
+                    if (a < 0 || d < 0 || (a & 7) != (d & 7)) continue;
+                    const int ba = (a & ITEM_ID_MASK) >> 3, bd = d >> 3;     // `a` may already carry its west link
+                    if (ba == bd || L->h_meta[(size_t)ba * NBR_STRIDE + DIR(1, 0, 0)] != bd) continue;
+                    cls[c][g + w] |= ITEM_LINK_E;
+                    cls[c][g + w + 1] |= ITEM_LINK_W;
+                }
+        }
         L->n_linked_items[part] = 0;
         for (int32_t it : cls[2])
             if (it >= 0 && (it & (ITEM_LINK_E | ITEM_LINK_W))) ++L->n_linked_items[part];
+    }
+    if (use_xrun && merge_classes(L, cls[1], cls[2])) {
+        // one launch for the whole pass: the all-neighbour workgroups ride along in the GENERAL instantiation (its patch
+        // phase finds nothing to do for them) - on small levels a launch boundary costs more than that
+        cls[2].insert(cls[2].end(), cls[1].begin(), cls[1].end());
+        cls[1].swap(cls[2]);
+        cls[2].clear();
     }
     for (int c = 0; c < N_CLASSES; ++c) {
         bool any = false;
         for (int32_t it : cls[c]) any = any || it >= 0;
         if (!any) cls[c].clear();
-        while (cls[c].size() % (c == 2 ? XRUN : 4)) cls[c].push_back(-1);
+        while (cls[c].size() % (c == 0 ? 4 : XRUN)) cls[c].push_back(-1);
         if (L->items[part][c]) { (void)hipFree(L->items[part][c]); L->items[part][c] = nullptr; }
         L->n_items[part][c] = (int64_t)cls[c].size();
         if (!cls[c].empty()) {
@@ -272,8 +295,9 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
 //    x-face columns handed over in LDS (kernels.hpp). Runs are cut greedily along every (by,bz) row of blocks.
 //  * MI355X deals workgroup g to XCD g % 8 (private L2 each): the 8 planes of a group occupy 8 consecutive slots,
 //    plane z on XCD (z + bz) % 8, so a line is fetched by one XCD only; groups are swept y-fastest, then x, then z.
-//  * blocks that do not fit a run (domain edges, refinement interfaces, leftovers) are stepped wave by wave,
-//    four blocks per workgroup, same slot rule.
+//  * chains shorter than a workgroup (leftovers, lone blocks) are packed several to a workgroup, same slot rule; a work
+//    item's link bits say which lateral faces arrive through LDS. Blocks with a missing neighbour (domain edges,
+//    refinement interfaces) are chained the same way among themselves and take the GENERAL instantiation.
 // Measured at 256^3 against the alternatives with tools/order_sweep.py (DESIGN.md "Launch order").
 int default_items(LudwigLevel *L, int part)
 {
@@ -291,76 +315,61 @@ int default_items(LudwigLevel *L, int part)
     });
     auto fast = [&](int b) { return (L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] & FLAG_ALL_NEIGHBOURS) != 0; };
     struct Group { int32_t by, bx0, bz; int32_t n; int32_t b[XRUN_MAX]; };
-    std::vector<Group> runs, shorts;      // full runs; leftover chains of 1 .. XRUN-1 all-neighbour blocks
-    std::vector<Blk> singles;             // blocks with a missing neighbour
+    // kind 0: all-neighbour blocks, kind 1: blocks with a missing neighbour. Chains never mix kinds (different kernels).
+    std::vector<Group> runs[2], shorts[2];      // full runs of XRUN; leftover chains of 1 .. XRUN-1 blocks
     size_t i = 0;
     while (i < blks.size()) {
-        // maximal chain of x-consecutive fast blocks starting at i (same by,bz row)
+        // maximal chain of x-consecutive blocks of one kind starting at i (same by,bz row)
         size_t j = i;
-        if (fast(blks[i].b)) {
-            while (j + 1 < blks.size() && blks[j + 1].by == blks[i].by && blks[j + 1].bz == blks[i].bz && fast(blks[j + 1].b) &&
-                   L->h_meta[(size_t)blks[j].b * NBR_STRIDE + DIR(1, 0, 0)] == blks[j + 1].b)
-                ++j;
-        }
+        const int kind = fast(blks[i].b) ? 0 : 1;
+        while (j + 1 < blks.size() && blks[j + 1].by == blks[i].by && blks[j + 1].bz == blks[i].bz && (fast(blks[j + 1].b) ? 0 : 1) == kind &&
+               L->h_meta[(size_t)blks[j].b * NBR_STRIDE + DIR(1, 0, 0)] == blks[j + 1].b && blks[j + 1].b != blks[i].b)
+            ++j;
         size_t k = i;
         for (; k + XRUN <= j + 1; k += XRUN) {
             Group g{blks[k].by, blks[k].bx, blks[k].bz, XRUN, {}};
             for (int w = 0; w < XRUN; ++w) g.b[w] = blks[k + w].b;
-            runs.push_back(g);
+            runs[kind].push_back(g);
         }
-        if (k <= j && fast(blks[k].b)) {
+        if (k <= j) {
             Group g{blks[k].by, blks[k].bx, blks[k].bz, (int32_t)(j + 1 - k), {}};
             for (size_t w = k; w <= j; ++w) g.b[w - k] = blks[w].b;
-            shorts.push_back(g);
-        } else {
-            for (; k <= j; ++k) singles.push_back(blks[k]);
+            shorts[kind].push_back(g);
         }
         i = j + 1;
     }
     // sweep: y fastest (y-neighbour groups re-read each other's face rows: next workgroup on the same XCD), then x, then z
-    std::sort(runs.begin(), runs.end(), [](const Group &a, const Group &c) {
+    auto by_zxy = [](const Group &a, const Group &c) {
         if (a.bz != c.bz) return a.bz < c.bz;
         if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
         return a.by < c.by;
-    });
-    std::sort(shorts.begin(), shorts.end(), [](const Group &a, const Group &c) {
-        if (a.bz != c.bz) return a.bz < c.bz;
-        if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
-        return a.by < c.by;
-    });
-    std::sort(singles.begin(), singles.end(), [](const Blk &a, const Blk &c) {
-        if (a.bz != c.bz) return a.bz < c.bz;
-        if (a.bx != c.bx) return a.bx < c.bx;
-        return a.by < c.by;
-    });
+    };
     // slot 8 * group + x runs on XCD x and steps plane z = (x - bz) mod 8: x/y neighbours (same bz, same plane) share an
     // XCD, and over bz every XCD sees every plane index, i.e. every value of address bits 8..10 (no L2-channel aliasing)
     std::vector<int32_t> seq;
-    for (const Group &g : runs)
-        for (int x = 0; x < 8; ++x) {
-            const int z = ((x - g.bz) % 8 + 8) % 8;
-            for (int w = 0; w < XRUN; ++w) seq.push_back((g.b[w] << 3) | z);
-        }
-    // leftover chains: whole chains packed into workgroups of XRUN waves (never split), same slot rule
-    for (size_t s0 = 0; s0 < shorts.size();) {
-        int32_t wg[XRUN_MAX];
-        int used = 0;
-        const int bz0 = shorts[s0].bz;
-        while (s0 < shorts.size() && used + shorts[s0].n <= XRUN) {
-            for (int w = 0; w < shorts[s0].n; ++w) wg[used++] = shorts[s0].b[w];
-            ++s0;
-        }
-        for (int x = 0; x < 8; ++x) {
-            const int z = ((x - bz0) % 8 + 8) % 8;
-            for (int w = 0; w < XRUN; ++w) seq.push_back(w < used ? (wg[w] << 3) | z : -1);
+    for (int kind = 0; kind < 2; ++kind) {
+        std::sort(runs[kind].begin(), runs[kind].end(), by_zxy);
+        std::sort(shorts[kind].begin(), shorts[kind].end(), by_zxy);
+        for (const Group &g : runs[kind])
+            for (int x = 0; x < 8; ++x) {
+                const int z = ((x - g.bz) % 8 + 8) % 8;
+                for (int w = 0; w < XRUN; ++w) seq.push_back((g.b[w] << 3) | z);
+            }
+        // leftover chains: whole chains packed into workgroups of XRUN waves (never split), same slot rule
+        for (size_t s0 = 0; s0 < shorts[kind].size();) {
+            int32_t wg[XRUN_MAX];
+            int used = 0;
+            const int bz0 = shorts[kind][s0].bz;
+            while (s0 < shorts[kind].size() && used + shorts[kind][s0].n <= XRUN) {
+                for (int w = 0; w < shorts[kind][s0].n; ++w) wg[used++] = shorts[kind][s0].b[w];
+                ++s0;
+            }
+            for (int x = 0; x < 8; ++x) {
+                const int z = ((x - bz0) % 8 + 8) % 8;
+                for (int w = 0; w < XRUN; ++w) seq.push_back(w < used ? (wg[w] << 3) | z : -1);
+            }
         }
     }
-    while (seq.size() % (8 * XRUN)) seq.push_back(-1);     // the wave-by-wave part below is laid out in workgroups of 4
-    for (size_t s0 = 0; s0 < singles.size(); s0 += 4)
-        for (int x = 0; x < 8; ++x) {
-            const int z = ((x - singles[s0].bz) % 8 + 8) % 8;
-            for (size_t w = 0; w < 4; ++w) seq.push_back(s0 + w < singles.size() ? (singles[s0 + w].b << 3) | z : -1);
-        }
     return set_items(L, part, seq.data(), (int64_t)seq.size());
 }
 
@@ -540,17 +549,20 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
         const hipStream_t cs = L->stream;
 #define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, cs, p)
-#define LW_LAUNCH_X(P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, cs, p); \
-            else hipLaunchKernelGGL((k_stream_collide_xrun<4, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, cs, p); } while (0)
+#define LW_LAUNCH_X(G, P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, cs, p); \
+            else hipLaunchKernelGGL((k_stream_collide_xrun<4, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, cs, p); } while (0)
         if (c == 0) {
             if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
             else      { if (wall) LW_LAUNCH(false, false, true); else LW_LAUNCH(false, false, false); }
-        } else if (c == 1) {
+        } else if (c == 1 && !L->general_in_runs[part]) {
             if (post) { if (wall) LW_LAUNCH(true, true, true); else LW_LAUNCH(true, true, false); }
             else      { if (wall) LW_LAUNCH(true, false, true); else LW_LAUNCH(true, false, false); }
+        } else if (c == 1) {
+            if (post) { if (wall) LW_LAUNCH_X(true, true, true); else LW_LAUNCH_X(true, true, false); }
+            else      { if (wall) LW_LAUNCH_X(true, false, true); else LW_LAUNCH_X(true, false, false); }
         } else {
-            if (post) { if (wall) LW_LAUNCH_X(true, true); else LW_LAUNCH_X(true, false); }
-            else      { if (wall) LW_LAUNCH_X(false, true); else LW_LAUNCH_X(false, false); }
+            if (post) { if (wall) LW_LAUNCH_X(false, true, true); else LW_LAUNCH_X(false, true, false); }
+            else      { if (wall) LW_LAUNCH_X(false, false, true); else LW_LAUNCH_X(false, false, false); }
         }
 #undef LW_LAUNCH_X
 #undef LW_LAUNCH

@@ -97,9 +97,15 @@ def test_result_does_not_depend_on_launch_order(gpu, order_name):
     compare(grids, dev, 4)
 
 
-def test_tunnel_interior_uses_x_runs(gpu):
+@pytest.mark.parametrize("merge", [None, "0", "1"])
+def test_tunnel_interior_uses_x_runs(gpu, monkeypatch, merge):
     """A tunnel long enough that interior all-neighbour blocks form x-runs: the x-run kernel then runs with obstacle,
-    sponge, Bouzidi (POST) and wall-model (WALL) work inside it."""
+    sponge, Bouzidi (POST) and wall-model (WALL) work inside it. merge "0": all-neighbour and edge blocks in separate
+    launches (what large levels do), "1" / default for this size: one launch, everything in the GENERAL instantiation."""
+    if merge is None:
+        monkeypatch.delenv("LUDWIG_MERGE_CLASSES", raising=False)
+    else:
+        monkeypatch.setenv("LUDWIG_MERGE_CLASSES", merge)
     grids, params = cases.tunnel_with_sphere((8, 4, 4), levels=1, wall_model=False)
     dev = run_both(grids, params, 3, 0.05)
     assert dev[0].info().n_xrun_blocks >= 16
@@ -128,6 +134,15 @@ def test_tunnel_sphere_bit_exact(gpu, levels, temporal):
     steps = 3
     dev = run_both(grids, params, steps, 0.05)
     compare(grids, dev, steps)
+
+
+def test_nested_levels_with_separate_launches_per_block_class(gpu, monkeypatch):
+    """Same 3-level case with LUDWIG_MERGE_CLASSES=0: all-neighbour blocks in the plain x-run instantiation, edge blocks in
+    the GENERAL one - the split large levels use."""
+    monkeypatch.setenv("LUDWIG_MERGE_CLASSES", "0")
+    grids, params = cases.tunnel_with_sphere((8, 4, 4), levels=3, wall_model=False, temporal=True)
+    dev = run_both(grids, params, 3, 0.05)
+    compare(grids, dev, 3)
 
 
 def test_tunnel_symmetric_no_blend(gpu):
