@@ -192,7 +192,7 @@ def _to_local(view: LocalView, global_off: np.ndarray, n_global: int) -> np.ndar
 @dataclass
 class HaloPlan:
     """Per peer: what to receive (local offsets into ghost blocks) and what to send (local offsets into owned blocks),
-    for 'f' and 'vel'. Receive lists are sorted by global offset, and send lists follow the receiver's order."""
+    per logical field (FIELD_GROUPS). Receive lists are sorted by global offset, and send lists follow the receiver's order."""
     peers: List[int] = field(default_factory=list)
     recv: Dict[int, Dict[str, np.ndarray]] = field(default_factory=dict)
     send: Dict[int, Dict[str, np.ndarray]] = field(default_factory=dict)
@@ -288,7 +288,7 @@ class HaloExchanger:
         self.exchange_fields({"f_post": "f_post_collision"})
 
     def exchange_fields(self, fields: Dict[str, str]) -> None:
-        """fields: logical halo group ('f' | 'vel' | 'f_post') -> name of the level field to move."""
+        """fields: logical halo group ('f' | 'vel' | 'f_post' | 'rho') -> name of the level field to move."""
         import torch.distributed as dist
         torch = self.torch
         names = tuple(fields)
