@@ -89,7 +89,7 @@ typedef struct LudwigLevelHost {
     const int8_t   *bouzidi_cell_x, *bouzidi_cell_y, *bouzidi_cell_z;   /* 1-based local coords     */
     const uint8_t  *comm_boundary; /* optional [n_blocks]: 1 = owned block adjacent to a ghost block */
     int32_t store_post_collision_everywhere;      /* 0: f_post_collision is written only where it has a reader - blocks that
-                                      hold a listed Bouzidi cell and their 26 neighbours (the reference writes it for every
+                                      hold a listed Bouzidi cell or a cell adjacent to one (the reference writes it for every
                                       cell, src/physics_kernels.jl:350-352, and reads it only there, src/bouzidi_kernel.jl:44-77).
                                       1: every block, as the reference (multi-GPU: a peer's cells read this rank's blocks)  */
 } LudwigLevelHost;

@@ -753,15 +753,21 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
             LW_HIP(hipMemcpy(L->cell_z, cz.data(), cz.size(), hipMemcpyHostToDevice));
         }
         if (L->has_post) {
-            // where f_post_collision has a reader: blocks with a Bouzidi cell and their 26 neighbours (a link q < 1/2 reads
+            // where f_post_collision has a reader: blocks that hold a Bouzidi cell or a cell next to one (a link q < 1/2 reads
             // the cell one step behind, possibly across a block face). No cell list on this rank (forced store, multi-GPU:
             // the readers are a peer's cells), store_post_collision_everywhere or LUDWIG_FULL_POST_COLLISION set: every block, as the reference.
             const bool everywhere = L->n_bc == 0 || h->store_post_collision_everywhere != 0 || getenv("LUDWIG_FULL_POST_COLLISION") != nullptr;
             for (int b = 0; b < L->n_blocks && everywhere; ++b) L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
             for (int i = 0; i < L->n_bc && !everywhere; ++i) {
+                // the cell itself and the 26 cells around it (a link reads f_post one cell behind the boundary cell)
                 const int32_t *row = &L->h_meta[(size_t)(h->bouzidi_cell_block[i] - 1) * NBR_STRIDE];
-                for (int d = 0; d < 27; ++d)
-                    if (row[d] >= 0) L->h_meta[(size_t)row[d] * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
+                const int x = h->bouzidi_cell_x[i] - 1, y = h->bouzidi_cell_y[i] - 1, z = h->bouzidi_cell_z[i] - 1;
+                for (int oz = (z == 0 ? -1 : 0); oz <= (z == 7 ? 1 : 0); ++oz)
+                    for (int oy = (y == 0 ? -1 : 0); oy <= (y == 7 ? 1 : 0); ++oy)
+                        for (int ox = (x == 0 ? -1 : 0); ox <= (x == 7 ? 1 : 0); ++ox) {
+                            const int nb2 = row[DIR(ox, oy, oz)];
+                            if (nb2 >= 0) L->h_meta[(size_t)nb2 * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
+                        }
             }
         }
         LW_HIP(hipStreamSynchronize(L->stream));

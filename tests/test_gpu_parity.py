@@ -29,9 +29,17 @@ def run_both(grids, params, steps, u, batch=None):
 
 
 def post_collision_blocks(g):
+    """blocks that hold a Bouzidi cell or a cell adjacent to one: where f_post_collision has a reader"""
     m = np.zeros(g.n_blocks, dtype=bool)
-    nb = np.asarray(g.neighbor_table)[np.unique(g.bouzidi_cell_block.astype(np.int64) - 1)]
-    m[nb[nb > 0] - 1] = True
+    cb = g.bouzidi_cell_block.astype(np.int64) - 1
+    xyz = [a.astype(np.int64) - 1 for a in (g.bouzidi_cell_x, g.bouzidi_cell_y, g.bouzidi_cell_z)]
+    nt = np.asarray(g.neighbor_table)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                o = [np.where(c + d < 0, -1, np.where(c + d > 7, 1, 0)) for c, d in zip(xyz, (dx, dy, dz))]
+                nb = nt[cb, (o[0] + 1) + 3 * (o[1] + 1) + 9 * (o[2] + 1)]
+                m[nb[nb > 0] - 1] = True
     return m
 
 
