@@ -731,82 +731,116 @@ __device__ __forceinline__ float weight_rt(int k)
     return d2 == 0 ? WEIGHT(13) : d2 == 1 ? WEIGHT(12) : d2 == 2 ? WEIGHT(9) : WEIGHT(0);
 }
 
+// The two sub-steps a child level takes per parent step see the SAME parent buffers and differ only in the temporal
+// weight (0.0 then 0.5, reference src/solver_control.jl:63-83). With TWO = true both values are produced from one set of
+// loads (second outputs mac2 / f_iface2 for weight tw2); the second sub-step then skips the pass.
+struct InterfaceArgs {
+    const int4 *corners;      // 2 per source: parent-cell offsets of the 8 stencil corners, -1 = absent (static, host)
+    const float4 *weights;    // per source: wx, wy, wz (static)
+    float4 *mac, *mac2;       // per source: interpolated rho, ux, uy, uz for tw / tw2
+    const int4 *links;        // per link: (block << 9) | cell, (gbi << 5) | k, source index
+    float *f_iface2;
+    float tw2;
+    int n_sources, n_links;
+};
+
+__device__ __forceinline__ float blend_in_time(bool blend, float v_old, float v_new, float tw)
+{
+    return blend ? v_old * (1.0f - tw) + v_new * tw : v_new;      // reference src/physics_interpolation.jl:83-93
+}
+
 // Pass 1, one thread per SOURCE cell (a fine-grid cell just outside this level's blocks): trilinear rho / u of
 // reference src/physics_interpolation.jl:64-124 - the same for every population pulled from that cell, so evaluated once.
-// The parent-cell offsets of the 8 corners and the weights are static (host, build_interface_links).
-__global__ __launch_bounds__(256) void k_interface_sources(const SCParams p, const int4 *__restrict__ corners, const float4 *__restrict__ weights,
-                                                            float4 *__restrict__ mac, int n_sources)
+template <bool TWO>
+__global__ __launch_bounds__(256) void k_interface_sources(const SCParams p, const InterfaceArgs a)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_sources) return;
-    const int4 c0 = corners[2 * i], c1 = corners[2 * i + 1];
+    if (i >= a.n_sources) return;
+    const int4 c0 = a.corners[2 * i], c1 = a.corners[2 * i + 1];
     const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const float4 w = weights[i];
-    const bool blend = p.use_temporal == 1 && p.temporal_weight < 0.99f;
-    const float tw = p.temporal_weight;
-    float rho_c[8], ux_c[8], uy_c[8], uz_c[8];
+    const float4 w = a.weights[i];
+    const float tw = p.temporal_weight, tw2 = a.tw2;
+    const bool blend = p.use_temporal == 1 && tw < 0.99f, blend2 = TWO && p.use_temporal == 1 && tw2 < 0.99f;
+    float v1[4][8], v2[4][8];                                  // rho, ux, uy, uz at the 8 corners
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        rho_c[n] = 1.0f; ux_c[n] = 0.0f; uy_c[n] = 0.0f; uz_c[n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
+        v1[0][n] = 1.0f; v1[1][n] = 0.0f; v1[2][n] = 0.0f; v1[3][n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
+        v2[0][n] = 1.0f; v2[1][n] = 0.0f; v2[2][n] = 0.0f; v2[3][n] = 0.0f;
         if (cc[n] >= 0) {
             const int c = cc[n];
-            const float rn = p.prho_new[c], un = p.pvel_new[c], vn = p.pvel_new[c + p.psk], wn = p.pvel_new[c + 2 * p.psk];
-            if (blend) {
-                rho_c[n] = p.prho_old[c] * (1.0f - tw) + rn * tw;
-                ux_c[n] = p.pvel_old[c] * (1.0f - tw) + un * tw;
-                uy_c[n] = p.pvel_old[c + p.psk] * (1.0f - tw) + vn * tw;
-                uz_c[n] = p.pvel_old[c + 2 * p.psk] * (1.0f - tw) + wn * tw;
-            } else {
-                rho_c[n] = rn; ux_c[n] = un; uy_c[n] = vn; uz_c[n] = wn;
+            const float vn[4] = {p.prho_new[c], p.pvel_new[c], p.pvel_new[c + p.psk], p.pvel_new[c + 2 * p.psk]};
+            float vo[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (blend || blend2) { vo[0] = p.prho_old[c]; vo[1] = p.pvel_old[c]; vo[2] = p.pvel_old[c + p.psk]; vo[3] = p.pvel_old[c + 2 * p.psk]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v1[q][n] = blend_in_time(blend, vo[q], vn[q], tw);
+                if (TWO) v2[q][n] = blend_in_time(blend2, vo[q], vn[q], tw2);
             }
         }
     }
     // invalid corners take corner 000's tuple (which may itself be the default), reference :100-107
 #pragma unroll
     for (int n = 1; n < 8; ++n)
-        if (cc[n] < 0) { rho_c[n] = rho_c[0]; ux_c[n] = ux_c[0]; uy_c[n] = uy_c[0]; uz_c[n] = uz_c[0]; }
-    mac[i] = make_float4(trilin(rho_c[0], rho_c[1], rho_c[2], rho_c[3], rho_c[4], rho_c[5], rho_c[6], rho_c[7], w.x, w.y, w.z),
-                         trilin(ux_c[0], ux_c[1], ux_c[2], ux_c[3], ux_c[4], ux_c[5], ux_c[6], ux_c[7], w.x, w.y, w.z),
-                         trilin(uy_c[0], uy_c[1], uy_c[2], uy_c[3], uy_c[4], uy_c[5], uy_c[6], uy_c[7], w.x, w.y, w.z),
-                         trilin(uz_c[0], uz_c[1], uz_c[2], uz_c[3], uz_c[4], uz_c[5], uz_c[6], uz_c[7], w.x, w.y, w.z));
+        if (cc[n] < 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v1[q][n] = v1[q][0]; v2[q][n] = v2[q][0]; }
+        }
+#define LW_TL(v, q) trilin(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5], v[q][6], v[q][7], w.x, w.y, w.z)
+    a.mac[i] = make_float4(LW_TL(v1, 0), LW_TL(v1, 1), LW_TL(v1, 2), LW_TL(v1, 3));
+    if (TWO) a.mac2[i] = make_float4(LW_TL(v2, 0), LW_TL(v2, 1), LW_TL(v2, 2), LW_TL(v2, 3));
+#undef LW_TL
 }
 
 // Pass 2, one thread per LINK (cell, population k): f_k interpolated over the same 8 corners, equilibrium from pass 1's
 // moments, non-equilibrium rescaled (reference src/physics_interpolation.jl:110-135). Expression by expression the
 // reference's interpolate_with_rescaling, so the value is bit-identical to the inline call.
-__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const int4 *__restrict__ corners, const float4 *__restrict__ weights,
-                                                          const float4 *__restrict__ mac, const int4 *__restrict__ links, int n_links)
+template <bool TWO>
+__global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const InterfaceArgs a)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n_links) return;
-    const int4 l = links[j];
+    if (j >= a.n_links) return;
+    const int4 l = a.links[j];
     const int cell = l.x & 511, k = l.y & 31, gbi = l.y >> 5, src = l.z;
-    const int4 c0 = corners[2 * src], c1 = corners[2 * src + 1];
+    const int4 c0 = a.corners[2 * src], c1 = a.corners[2 * src + 1];
     const int cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    const float4 w = weights[src];
-    const float4 m = mac[src];
-    const bool blend = p.use_temporal == 1 && p.temporal_weight < 0.99f;
-    const float tw = p.temporal_weight;
+    const float4 w = a.weights[src];
+    const float tw = p.temporal_weight, tw2 = a.tw2;
+    const bool blend = p.use_temporal == 1 && tw < 0.99f, blend2 = TWO && p.use_temporal == 1 && tw2 < 0.99f;
     const float w_k = weight_rt(k);
     const int64_t koff = p.psk * k;
-    float fc[8];
+    float fc[8], fc2[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
-        fc[n] = w_k;
+        fc[n] = w_k; fc2[n] = w_k;
         if (cc[n] >= 0) {
             const float fn = p.pf_new[(int64_t)cc[n] + koff];
-            fc[n] = blend ? p.pf_old[(int64_t)cc[n] + koff] * (1.0f - tw) + fn * tw : fn;
+            float fo = 0.0f;
+            if (blend || blend2) fo = p.pf_old[(int64_t)cc[n] + koff];
+            fc[n] = blend_in_time(blend, fo, fn, tw);
+            if (TWO) fc2[n] = blend_in_time(blend2, fo, fn, tw2);
         }
     }
 #pragma unroll
     for (int n = 1; n < 8; ++n)
-        if (cc[n] < 0) fc[n] = fc[0];
-    const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], w.x, w.y, w.z);
-    const float feq_int = calculate_equilibrium(m.x, m.y, m.z, m.w, w_k, (float)(k % 3 - 1), (float)((k / 3) % 3 - 1), (float)(k / 9 - 1));
-    const float f_neq = f_int - feq_int;
+        if (cc[n] < 0) { fc[n] = fc[0]; fc2[n] = fc2[0]; }
+    const float cxf = (float)(k % 3 - 1), cyf = (float)((k / 3) % 3 - 1), czf = (float)(k / 9 - 1);
     const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
     const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
-    p.f_iface[((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell] = feq_int + f_neq * scale;
+    const size_t out = ((size_t)k * p.n_iface_blocks + gbi) * CELLS + cell;
+    {
+        const float4 m = a.mac[src];
+        const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], w.x, w.y, w.z);
+        const float feq_int = calculate_equilibrium(m.x, m.y, m.z, m.w, w_k, cxf, cyf, czf);
+        const float f_neq = f_int - feq_int;
+        p.f_iface[out] = feq_int + f_neq * scale;
+    }
+    if (TWO) {
+        const float4 m = a.mac2[src];
+        const float f_int = trilin(fc2[0], fc2[1], fc2[2], fc2[3], fc2[4], fc2[5], fc2[6], fc2[7], w.x, w.y, w.z);
+        const float feq_int = calculate_equilibrium(m.x, m.y, m.z, m.w, w_k, cxf, cyf, czf);
+        const float f_neq = f_int - feq_int;
+        a.f_iface2[out] = feq_int + f_neq * scale;
+    }
 }
 
 // ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----

@@ -81,6 +81,19 @@ struct LudwigLevel {
     int4 *sources[N_PARTS] = {};        // per source cell: 8 parent-cell offsets of its trilinear stencil (-1 = absent), 2 x int4
     float4 *source_w[N_PARTS] = {};     // per source cell: interpolation weights wx, wy, wz
     float4 *source_mac[N_PARTS] = {};   // per source cell, rewritten every pass: interpolated rho, ux, uy, uz
+    float4 *source_mac2[N_PARTS] = {};  // the same for the speculated weight of the next sub-step
+    float *f_iface2 = nullptr;
+    // Interface values computed ahead for the second sub-step of a pair (reference src/solver_control.jl:63-83: the child
+    // steps 2t with weight 0.0 and 2t+1 with 0.5 against the same parent buffers): valid while the parent was not written.
+    struct IfaceAhead {
+        bool valid = false;
+        const LudwigLevel *parent = nullptr;
+        uint64_t parent_version = 0;
+        int64_t t_sub = 0;            // the sub-step the speculated values are for
+        float tw = 0.0f, tau_parent = 0.0f;
+        int use_temporal = 0;
+    } ahead[N_PARTS];
+    uint64_t version = 0;               // bumped by everything that writes this level's fields
     const LudwigLevel *iface_parent = nullptr;
     std::vector<int32_t> h_block_pointer;   // [gdx,gdy,gdz] 1-based, 0 = absent (src/blocks.jl:111-114)
     int n_links[N_PARTS] = {};
@@ -117,6 +130,7 @@ struct FieldDesc {
 int materialize_old(LudwigLevel *L)
 {
     if (L->old_alias < 0) return LUDWIG_OK;
+    ++L->version;
     const size_t c = (size_t)L->sk;
     const int a = L->old_alias;
     L->old_alias = -1;
@@ -445,7 +459,9 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
         // read neighbouring parent cells of ONE population array (a few 128-B lines per wave-load instead of ~30) and
         // write neighbouring cells of f_iface.
         std::stable_sort(links.begin(), links.end(), [](const int4 &u, const int4 &v) { return (u.y & 31) < (v.y & 31); });
-        void **owned[] = {(void **)&L->links[a2], (void **)&L->sources[a2], (void **)&L->source_w[a2], (void **)&L->source_mac[a2]};
+        L->ahead[a2].valid = false;
+        void **owned[] = {(void **)&L->links[a2], (void **)&L->sources[a2], (void **)&L->source_w[a2], (void **)&L->source_mac[a2],
+                          (void **)&L->source_mac2[a2]};
         for (void **q : owned)
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         L->n_links[a2] = (int)links.size();
@@ -458,11 +474,13 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
             LW_HIP(hipMalloc((void **)&L->source_w[a2], weights.size() * sizeof(float4)));
             LW_HIP(hipMemcpy(L->source_w[a2], weights.data(), weights.size() * sizeof(float4), hipMemcpyHostToDevice));
             LW_HIP(hipMalloc((void **)&L->source_mac[a2], weights.size() * sizeof(float4)));
+            LW_HIP(hipMalloc((void **)&L->source_mac2[a2], weights.size() * sizeof(float4)));
         }
     }
     if (!L->f_iface && L->n_iface_blocks > 0) {
         LW_HIP(hipMalloc((void **)&L->f_iface, (size_t)L->n_iface_blocks * CELLS * Q * sizeof(float)));
-        L->device_bytes += (int64_t)L->n_iface_blocks * CELLS * Q * 4;
+        LW_HIP(hipMalloc((void **)&L->f_iface2, (size_t)L->n_iface_blocks * CELLS * Q * sizeof(float)));
+        L->device_bytes += 2 * (int64_t)L->n_iface_blocks * CELLS * Q * 4;
     }
     L->iface_parent = parent;
     L->iface_dims[0] = nx_g; L->iface_dims[1] = ny_g; L->iface_dims[2] = nz_g;
@@ -479,6 +497,7 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     if (parent && parent->device != L->device) return fail(LUDWIG_ERR_INVALID, "parent level lives on another device");
     LW_HIP(hipSetDevice(L->device));
     const int in = (t_sub % 2 == 0) ? 0 : 1, out = 1 - in;   // reference src/solver_control.jl:35-41
+    ++L->version;                                            // this level's fields are about to change
     if (L->old_alias == out) {                               // about to overwrite the buffer that holds the saved state
         const int r = materialize_old(L);
         if (r) return r;
@@ -536,11 +555,34 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         p.f_iface = L->f_iface;
         p.n_iface_blocks = L->n_iface_blocks;
         if (L->n_links[part] > 0) {
-            hipLaunchKernelGGL(k_interface_sources, dim3((unsigned)((L->n_sources[part] + 255) / 256)), dim3(256), 0, L->stream, p,
-                               L->sources[part], L->source_w[part], L->source_mac[part], L->n_sources[part]);
-            hipLaunchKernelGGL(k_interface_links, dim3((unsigned)((L->n_links[part] + 255) / 256)), dim3(256), 0, L->stream, p,
-                               L->sources[part], L->source_w[part], L->source_mac[part], L->links[part], L->n_links[part]);
-            LW_HIP(hipGetLastError());
+            LudwigLevel::IfaceAhead &ah = L->ahead[part];
+            const bool hit = ah.valid && ah.parent == parent && ah.parent_version == parent->version && ah.t_sub == t_sub &&
+                             ah.tw == temporal_weight && ah.tau_parent == parent_tau && ah.use_temporal == p.use_temporal;
+            ah.valid = false;
+            if (hit) {
+                p.f_iface = L->f_iface2;          // computed together with the previous sub-step's values
+            } else {
+                // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
+                const bool two = (t_sub % 2 == 0) && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
+                InterfaceArgs a{};
+                a.corners = L->sources[part]; a.weights = L->source_w[part];
+                a.mac = L->source_mac[part]; a.mac2 = L->source_mac2[part];
+                a.links = L->links[part];
+                a.f_iface2 = L->f_iface2;
+                a.tw2 = 0.5f;
+                a.n_sources = L->n_sources[part]; a.n_links = L->n_links[part];
+                const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
+                if (two) {
+                    hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, L->stream, p, a);
+                    hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, L->stream, p, a);
+                    ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
+                    ah.tw = a.tw2; ah.tau_parent = parent_tau; ah.use_temporal = p.use_temporal;
+                } else {
+                    hipLaunchKernelGGL(k_interface_sources<false>, gs, dim3(256), 0, L->stream, p, a);
+                    hipLaunchKernelGGL(k_interface_links<false>, gl, dim3(256), 0, L->stream, p, a);
+                }
+                LW_HIP(hipGetLastError());
+            }
         }
     }
     for (int c = 0; c < N_CLASSES; ++c) {
@@ -575,6 +617,7 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
 {
     if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
     if (!(L->bouzidi_enabled && L->n_bc > 0)) return LUDWIG_OK;   // reference src/bouzidi_kernel.jl:107-109
+    ++L->version;
     LW_HIP(hipSetDevice(L->device));
     const int out = (t_sub % 2 == 0) ? 1 : 0;
     BouzidiParams p{};
@@ -625,8 +668,10 @@ void ludwig_level_destroy(LudwigLevel *L)
         if (L->sources[a]) (void)hipFree(L->sources[a]);
         if (L->source_w[a]) (void)hipFree(L->source_w[a]);
         if (L->source_mac[a]) (void)hipFree(L->source_mac[a]);
+        if (L->source_mac2[a]) (void)hipFree(L->source_mac2[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
+    if (L->f_iface2) (void)hipFree(L->f_iface2);
     delete L;
 }
 
@@ -820,6 +865,7 @@ int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t byte
     if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
     if (bytes != d.bytes) return fail(LUDWIG_ERR_INVALID, "field %d: got %zu bytes, expected %zu", field, bytes, d.bytes);
     LW_HIP(hipSetDevice(L->device));
+    ++L->version;
     {
         const int r = before_external_write(L, field);
         if (r) return r;
@@ -848,6 +894,7 @@ int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t by
 int ludwig_level_field_ptr(const LudwigLevel *L, int field, void **device_ptr, size_t *bytes)
 {
     if (!L || !device_ptr) return fail(LUDWIG_ERR_INVALID, "null argument");
+    ++const_cast<LudwigLevel *>(L)->version;
     {   // the caller may write through the pointer: give the saved state its own storage first
         const int r = before_external_write(const_cast<LudwigLevel *>(L), field);
         if (r) return r;
@@ -865,6 +912,7 @@ int ludwig_init_equilibrium(LudwigLevel *L)
     if (L->n_blocks == 0) return LUDWIG_OK;
     LW_HIP(hipSetDevice(L->device));
     const unsigned grid = (unsigned)((L->sk + 255) / 256);
+    ++L->version;
     hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[0], L->sk);
     hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[1], L->sk);
     if (L->has_temporal) {
@@ -902,6 +950,7 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
     const int in = (t_sub % 2 == 0) ? 0 : 1;
     const size_t c = (size_t)L->sk;
     // f and vel: no copy - the step that follows reads f[in] / vel[in] and never writes them (see old_alias)
+    ++L->version;
     L->old_alias = in;
     LW_HIP(hipMemcpyAsync(L->rho_old, L->rho, c * 4, hipMemcpyDeviceToDevice, L->stream));
     return LUDWIG_OK;
@@ -1009,6 +1058,7 @@ int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int6
 {
     if (!L || (n > 0 && (!index_dev || !src_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
     if (n == 0) return LUDWIG_OK;
+    ++L->version;
     {
         const bool aliased = L->old_alias >= 0;
         const int r = before_external_write(L, field);

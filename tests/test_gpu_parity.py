@@ -242,3 +242,31 @@ def test_post_collision_store_modes(gpu):
         results.append(d.download("f"))
         compare(grids, dev, 3)
     assert np.array_equal(results[0], results[1])
+
+
+def test_interface_values_computed_ahead_are_dropped_when_the_parent_changes(gpu, monkeypatch):
+    """The first sub-step of a pair also produces the interface values of the second one (same parent buffers, weight 0.5).
+    If anything writes the parent in between, they must be recomputed: the sequence with an upload into the parent between
+    the two child sub-steps gives the same child state as with the look-ahead switched off."""
+    from open_ludwig_amd.physics import perform_timestep_v2
+    results = []
+    for ahead in (True, False):
+        if ahead:
+            monkeypatch.delenv("LUDWIG_NO_IFACE_AHEAD", raising=False)
+        else:
+            monkeypatch.setenv("LUDWIG_NO_IFACE_AHEAD", "1")
+        grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=2, wall_model=False, temporal=True)
+        for g in grids:
+            cases.init_perturbed(g, seed=11 + g.level_id)
+        dev = [adapt(g, 0) for g in grids]
+        u = np.float32(0.05)
+        dev[0].copy_to_old(2)
+        perform_timestep_v2(dev[0], None, np.float32(0.5), u, params, 2, np.float32(0.0))                 # parent: writes f_temp
+        perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 4, np.float32(0.0))                    # child, first of the pair
+        newer = dev[0].download("f_temp")
+        dev[0].upload("f_temp", (newer * np.float32(1.01)).astype(np.float32))                            # the parent changes
+        perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 5, np.float32(0.5))                    # child, second of the pair
+        results.append((dev[1].download("f"), dev[1].download("rho")))
+        for d in dev:
+            d.close()
+    assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
