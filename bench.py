@@ -187,7 +187,7 @@ def main():
                        "state_finite": ok},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "lw::k_stream_collide_xrun<4,false,false>", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "lw::k_stream_collide_xrun<4,false,false,false> (NW, GENERAL, POST, WALL)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_LUP * cells_per_rank,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"},
         }
