@@ -207,11 +207,12 @@ int  ludwig_halo_unpack(LudwigLevel *level, int field, const int64_t *index_dev,
 /* ---- introspection for benchmarks ---- */
 typedef struct LudwigLevelInfo {
     int32_t n_blocks, n_owned;
-    int32_t n_fast_blocks;        /* owned blocks with all 26 neighbours present (branch-free pull kernel) */
+    int32_t n_fast_blocks;        /* owned blocks with all 26 neighbours present (no edge / interface patching)   */
     int32_t n_general_blocks;
     int32_t n_boundary_cells;
     int32_t has_temporal_storage, has_post_collision;
-    int32_t n_xrun_blocks;        /* of the fast blocks: how many the current LUDWIG_PART_ALL order steps in x-runs of 4 */
+    int32_t n_xrun_blocks;        /* of the fast blocks: how many the current LUDWIG_PART_ALL order steps next to an x
+                                     neighbour in the same workgroup (face column through LDS instead of global memory) */
     int64_t device_bytes;
 } LudwigLevelInfo;
 int  ludwig_level_info(const LudwigLevel *level, LudwigLevelInfo *info);
