@@ -87,7 +87,8 @@ def main():
             holder["st"] = case.DistributedStepper(grids, device=0, stage_through_host=True)
             return holder["st"]
 
-        rows, rep, _ = case.run_case(cfg, factory, steps=steps, setup=setup)
+        cfg.output_freq = 40
+        rows, rep, _ = case.run_case(cfg, factory, steps=steps, setup=setup, out_dir=os.path.join(outdir, "results"), write_files=(rank == 0))
         st = holder["st"]
         stats = [[v.n_owned, v.level.n_blocks, st.runner.ex[i].plan.bytes_per_step()] for i, v in enumerate(st.runner.views)]
         if rank == 0:

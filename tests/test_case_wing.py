@@ -87,3 +87,13 @@ def test_wing_on_two_ranks_equals_single_device(gpu, wing, tmp_path):
     assert len(rows) == len(single) == 3
     for got, want in zip(rows, single):
         assert got == [want.step, want.u_lat, want.rho_min, want.cd, want.cl, want.cs, want.cmy], (got, want)
+    # result files: written once (rank 0), from fields gathered over both ranks
+    from test_output_files import read_vtu
+    from open_ludwig_amd import output
+    res = os.path.join(tmp_path, "results")
+    assert sorted(os.listdir(res)) == ["convergence.csv", "flow_000040.vtu", "forces.csv", "surface_000040.vtu"]
+    assert len(open(os.path.join(res, "forces.csv")).read().splitlines()) == 4
+    grids = pp.setup_multilevel_domain(cfg, stl)[0]
+    d = read_vtu(os.path.join(res, "flow_000040.vtu"))
+    assert d["n_cells"] == 512 * len(output.select_export_blocks([g.active_block_coords for g in grids]))
+    assert np.isfinite(d["Velocity"]).all() and np.abs(d["Velocity"]).max() > 0 and "Density" not in d      # density: false in this case's config
