@@ -854,18 +854,30 @@ struct BouzidiParams {
     int64_t sk;
     int32_t n_cells;
     float q_min;
+    const int2 *links;           // compact list of the links with q > 0: (block * 512 + cell, k); nullptr = all (cell, k)
+    int32_t n_links;
 };
 
 // one thread per (listed cell, link k): the 27 links of a cell are independent (each writes its own f_out[cell][opp k]
 // and reads only f_post_collision), so spreading them over lanes changes nothing but the latency that is exposed
+// With a link list (the q map is static, so the host lists the links with q > 0 once) the threads that would only find
+// q = 0 - four out of five - do not exist; q_min is still applied here, per call.
 __global__ __launch_bounds__(256) void k_bouzidi(const BouzidiParams p)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= p.n_cells * Q) return;
-    const int c = i / Q, k = i - c * Q;
+    int b, x, y, z, k;
+    if (p.links) {
+        if (i >= p.n_links) return;
+        const int2 l = p.links[i];
+        b = l.x >> 9; x = l.x & 7; y = (l.x >> 3) & 7; z = (l.x >> 6) & 7; k = l.y;
+    } else {
+        if (i >= p.n_cells * Q) return;
+        const int c = i / Q;
+        k = i - c * Q;
+        b = p.cell_block[c];
+        x = p.cell_x[c]; y = p.cell_y[c]; z = p.cell_z[c];
+    }
     const int opp_k = 26 - k;
-    const int b = p.cell_block[c];
-    const int x = p.cell_x[c], y = p.cell_y[c], z = p.cell_z[c];
     const int64_t own = (int64_t)b * CELLS + x + 8 * y + 64 * z;
     const float q = (float)p.q_map[own + p.sk * k];
     if (q > p.q_min && q <= 1.0f) {

@@ -63,6 +63,8 @@ struct LudwigLevel {
     // saved state lives in f_old / vel_old (materialize_old() copies it there before any such write). rho is copied.
     int old_alias = -1;
     int n_bc = 0;
+    int2 *bouzidi_links = nullptr;      // (block * 512 + cell, k) of every listed link with q > 0 (the q map is static)
+    int n_bouzidi_links = 0;
     _Float16 *q_map = nullptr;
     int32_t *cell_block = nullptr;
     int8_t *cell_x = nullptr, *cell_y = nullptr, *cell_z = nullptr;
@@ -629,8 +631,14 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
     p.meta = L->meta;
     p.sk = L->sk;
     p.n_cells = L->n_bc;
+    // q > q_min with q_min >= 0 can only hold where q > 0: the compact list; a negative threshold takes every (cell, k)
+    const bool compact = q_min >= 0.0f && L->bouzidi_links;
+    p.links = compact ? L->bouzidi_links : nullptr;
+    p.n_links = L->n_bouzidi_links;
     p.q_min = q_min;
-    hipLaunchKernelGGL(k_bouzidi, dim3((unsigned)(((int64_t)L->n_bc * Q + 255) / 256)), dim3(256), 0, L->stream, p);
+    const int64_t n_threads = compact ? (int64_t)L->n_bouzidi_links : (int64_t)L->n_bc * Q;
+    if (n_threads == 0) return LUDWIG_OK;
+    hipLaunchKernelGGL(k_bouzidi, dim3((unsigned)((n_threads + 255) / 256)), dim3(256), 0, L->stream, p);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -671,6 +679,7 @@ void ludwig_level_destroy(LudwigLevel *L)
         if (L->source_mac2[a]) (void)hipFree(L->source_mac2[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
+    if (L->bouzidi_links) (void)hipFree(L->bouzidi_links);
     if (L->f_iface2) (void)hipFree(L->f_iface2);
     delete L;
 }
@@ -796,6 +805,18 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
             LW_HIP(hipMemcpy(L->cell_x, cx.data(), cx.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_y, cy.data(), cy.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_z, cz.data(), cz.size(), hipMemcpyHostToDevice));
+            std::vector<int2> bl;
+            const _Float16 *qh = reinterpret_cast<const _Float16 *>(h->bouzidi_q_map);
+            for (int i = 0; i < L->n_bc; ++i) {
+                const int own = cb[i] * CELLS + cx[i] + 8 * cy[i] + 64 * cz[i];
+                for (int k = 0; k < Q; ++k)
+                    if ((float)qh[(size_t)own + (size_t)c * k] > 0.0f) bl.push_back(make_int2(own, k));
+            }
+            L->n_bouzidi_links = (int)bl.size();
+            if (!bl.empty()) {
+                LW_HIP(hipMalloc((void **)&L->bouzidi_links, bl.size() * sizeof(int2)));
+                LW_HIP(hipMemcpy(L->bouzidi_links, bl.data(), bl.size() * sizeof(int2), hipMemcpyHostToDevice));
+            }
         }
         if (L->has_post) {
             // where f_post_collision has a reader: blocks that hold a Bouzidi cell or a cell next to one (a link q < 1/2 reads
