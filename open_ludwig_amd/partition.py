@@ -480,7 +480,8 @@ def ancestor_owner(level_id: int, coords, level1_coords, level1_owner: np.ndarra
 
 def balanced_owner(grids: Sequence[BlockLevel], world: int) -> np.ndarray:
     """Owner of every level-1 block for nested levels: recursive coordinate bisection with planar cuts, weighted by the
-    work below each level-1 block (its own step + 2^(l-1) sub-steps of every level-l descendant block per coarse step)."""
+    work below each level-1 block (its own step + 2^(l-1) sub-steps of every level-l descendant block per coarse step);
+    every cut takes the axis and plane that split the work best (ties: the longer axis)."""
     c1 = np.asarray(grids[0].active_block_coords, dtype=np.int64)
     lut = {tuple(c): i for i, c in enumerate(c1)}
     w = np.ones(len(c1), dtype=np.float64)
@@ -495,16 +496,19 @@ def balanced_owner(grids: Sequence[BlockLevel], world: int) -> np.ndarray:
             return
         n_lo = n // 2
         ext = c1[ids].max(axis=0) - c1[ids].min(axis=0)
-        best = None
-        for axis in np.argsort(-ext, kind="stable"):
+        target = w[ids].sum() * n_lo / n
+        best = None                            # (imbalance, -extent, axis, plane): the best balanced cut of the three axes
+        for axis in range(3):
             planes = np.unique(c1[ids, axis])
             if planes.size < 2:
                 continue
             below = np.array([w[ids][c1[ids, axis] <= p].sum() for p in planes[:-1]])
-            target = w[ids].sum() * n_lo / n
             j = int(np.argmin(np.abs(below - target)))
-            best = (axis, planes[j])
-            break
+            cand = (float(abs(below[j] - target)), -int(ext[axis]), axis, planes[j])
+            if best is None or cand[:2] < best[:2]:
+                best = cand
+        if best is not None:
+            best = (best[2], best[3])
         if best is None:                       # a single block column left: nothing to cut
             owner[ids] = r0
             return
