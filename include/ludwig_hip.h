@@ -72,7 +72,8 @@ typedef struct LudwigLevel LudwigLevel;   /* opaque; owns all device memory of o
 typedef struct LudwigLevelHost {
     int32_t level_id;              /* 1-based, BlockLevel.level_id                                  */
     int32_t n_blocks;              /* blocks in the arrays = owned blocks followed by ghost blocks  */
-    int32_t n_owned;               /* blocks this device steps; 0 means n_blocks (single device)    */
+    int32_t n_owned;               /* blocks this device steps; 0 means n_blocks (single device),
+                                      < 0 means none (the level only holds ghost copies here)        */
     float   tau;                   /* BlockLevel.tau                                                */
     int32_t grid_dim_x, grid_dim_y, grid_dim_z;   /* size(block_pointer)                            */
     const int32_t *block_pointer;  /* [dim_x,dim_y,dim_z], 1-based, 0 = absent (src/blocks.jl:111-114) */

@@ -201,7 +201,8 @@ class DeviceLevel:
         h = _lib.LevelHost()
         h.level_id = host.level_id
         h.n_blocks = host.n_blocks
-        h.n_owned = int(host.n_owned) if host.n_owned != host.n_blocks else 0
+        # ABI: 0 = all blocks owned (single device), -1 = none (a level this rank only holds ghost copies of)
+        h.n_owned = (int(host.n_owned) if host.n_owned > 0 else -1) if host.n_owned != host.n_blocks else 0
         h.tau = float(host.tau)
         h.grid_dim_x, h.grid_dim_y, h.grid_dim_z = host.grid_dim_x, host.grid_dim_y, host.grid_dim_z
         h.block_pointer = ptr(host.block_pointer, np.int32) if host.block_pointer.size else None

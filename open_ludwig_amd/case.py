@@ -60,23 +60,23 @@ class HipStepper:
 
 class DistributedStepper:
     """grids spread over the ranks of the default torch.distributed group, one MI355X per rank (scope row N3): every
-    level is cut by the owner of its level-1 ancestor (partition.balanced_owner), halo + parent-data ghosts move after
-    every level step (partition.MultiLevelRunner). `field()` returns the GLOBAL array on every rank (owned blocks
-    all-gathered), so the diagnostics of run_case are computed exactly as in the single-device run."""
+    level is cut on its own into equal parts (partition.level_owners; pass `owners` to choose otherwise), halo +
+    parent-data ghosts move after every level step (partition.MultiLevelRunner). `field()` returns the GLOBAL array on
+    every rank (owned blocks all-gathered), so the diagnostics of run_case are computed exactly as in the single-device run."""
 
-    def __init__(self, host_grids, device: Optional[int] = None, owner_level1: Optional[np.ndarray] = None, stage_through_host: bool = False):
+    def __init__(self, host_grids, device: Optional[int] = None, owners=None, stage_through_host: bool = False):
         import torch.distributed as dist
         from . import partition
         self.dist, self.partition = dist, partition
         self.host = host_grids
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device if device is not None else int(__import__("os").environ.get("LOCAL_RANK", "0"))
-        self.owner1 = owner_level1 if owner_level1 is not None else partition.balanced_owner(host_grids, self.world)
+        self.owners = owners if owners is not None else partition.level_owners(host_grids, self.world)
         self.stage = stage_through_host
         self.runner = None
 
     def _start(self, params) -> None:
-        self.runner = self.partition.MultiLevelRunner(self.host, self.owner1, params, self.rank, self.world, self.device, self.stage)
+        self.runner = self.partition.MultiLevelRunner(self.host, self.owners, params, self.rank, self.world, self.device, self.stage)
         for lv in self.runner.levels:
             if lv is not None:
                 lv.init_equilibrium()          # src/main.jl:126-135 (ghost blocks included: same rest state everywhere)

@@ -691,7 +691,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     if (h->n_blocks < 0 || h->level_id < 1 || h->level_id > 30) return fail(LUDWIG_ERR_INVALID, "bad n_blocks/level_id");
     if (h->n_blocks > 0 && (!h->neighbor_table || !h->map_x || !h->map_y || !h->map_z)) return fail(LUDWIG_ERR_INVALID, "neighbor_table and map_x/y/z are required");
     if ((int64_t)h->n_blocks * CELLS * 4 >= (int64_t)1 << 32) return fail(LUDWIG_ERR_INVALID, "n_blocks too large for 32-bit byte offsets (max 2^21 - 1 blocks per level)");
-    const int n_owned = h->n_owned > 0 ? h->n_owned : h->n_blocks;
+    const int n_owned = h->n_owned > 0 ? h->n_owned : (h->n_owned < 0 ? 0 : h->n_blocks);
     if (n_owned > h->n_blocks) return fail(LUDWIG_ERR_INVALID, "n_owned > n_blocks");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(LUDWIG_ERR_NO_DEVICE, "no HIP device visible");

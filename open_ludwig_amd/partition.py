@@ -42,8 +42,10 @@ class LocalView:
 
 
 def build_local_level(level_id: int, coords: Sequence[Tuple[int, int, int]], neighbor_table: np.ndarray, owner: np.ndarray,
-                      rank: int, tau: float, temporal: bool = False) -> LocalView:
-    """Cut rank `rank`'s local level out of the global block list (coords + global neighbor_table, 1-based)."""
+                      rank: int, tau: float, temporal: bool = False, extra_ghosts: Optional[np.ndarray] = None) -> LocalView:
+    """Cut rank `rank`'s local level out of the global block list (coords + global neighbor_table, 1-based).
+    extra_ghosts: further remote blocks (global ids, 0-based) to keep a ghost copy of - parent data of this rank's finer
+    blocks (required_parent_blocks)."""
     coords = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
     owner = np.asarray(owner)
     nt = np.asarray(neighbor_table)
@@ -51,6 +53,9 @@ def build_local_level(level_id: int, coords: Sequence[Tuple[int, int, int]], nei
     nbrs = nt[owned].reshape(-1)
     nbrs = np.unique(nbrs[nbrs > 0]) - 1
     ghosts = nbrs[owner[nbrs] != rank]
+    if extra_ghosts is not None and len(extra_ghosts):
+        extra = np.asarray(extra_ghosts, dtype=np.int64)
+        ghosts = np.unique(np.concatenate([ghosts, extra[owner[extra] != rank]]))
     l2g = np.concatenate([owned, ghosts])
     g2l = np.full(len(coords) + 1, 0, dtype=np.int64)            # 1-based global -> 1-based local, 0 = absent
     g2l[l2g + 1] = np.arange(1, len(l2g) + 1)
@@ -478,16 +483,11 @@ def ancestor_owner(level_id: int, coords, level1_coords, level1_owner: np.ndarra
     return np.array([lut[(int(a) + 1, int(b) + 1, int(d) + 1)] for a, b, d in c], dtype=np.int64)
 
 
-def balanced_owner(grids: Sequence[BlockLevel], world: int) -> np.ndarray:
-    """Owner of every level-1 block for nested levels: recursive coordinate bisection with planar cuts, weighted by the
-    work below each level-1 block (its own step + 2^(l-1) sub-steps of every level-l descendant block per coarse step);
-    every cut takes the axis and plane that split the work best (ties: the longer axis)."""
-    c1 = np.asarray(grids[0].active_block_coords, dtype=np.int64)
-    lut = {tuple(c): i for i, c in enumerate(c1)}
-    w = np.ones(len(c1), dtype=np.float64)
-    for g in grids[1:]:
-        anc = ((np.asarray(g.active_block_coords, dtype=np.int64).reshape(-1, 3) - 1) >> (g.level_id - 1)) + 1
-        np.add.at(w, [lut[tuple(a)] for a in anc], float(2 ** (g.level_id - 1)))
+def bisect_owner(coords, weights, world: int) -> np.ndarray:
+    """Recursive coordinate bisection of a block set with planar cuts between blocks: every cut takes the axis and plane
+    that split the weight best (ties: the longer axis); rank ranges are halved alongside (any world size)."""
+    c1 = np.asarray(coords, dtype=np.int64).reshape(-1, 3)
+    w = np.asarray(weights, dtype=np.float64)
     owner = np.zeros(len(c1), dtype=np.int64)
 
     def split(ids: np.ndarray, r0: int, n: int) -> None:
@@ -507,18 +507,55 @@ def balanced_owner(grids: Sequence[BlockLevel], world: int) -> np.ndarray:
             cand = (float(abs(below[j] - target)), -int(ext[axis]), axis, planes[j])
             if best is None or cand[:2] < best[:2]:
                 best = cand
-        if best is not None:
-            best = (best[2], best[3])
-        if best is None:                       # a single block column left: nothing to cut
+        if best is None:                       # a single block left: nothing to cut
             owner[ids] = r0
             return
-        lo = ids[c1[ids, best[0]] <= best[1]]
-        hi = ids[c1[ids, best[0]] > best[1]]
+        lo = ids[c1[ids, best[2]] <= best[3]]
+        hi = ids[c1[ids, best[2]] > best[3]]
         split(lo, r0, n_lo)
         split(hi, r0 + n_lo, n - n_lo)
 
     split(np.arange(len(c1)), 0, world)
     return owner
+
+
+def balanced_owner(grids: Sequence[BlockLevel], world: int) -> np.ndarray:
+    """Owner of every level-1 block when whole hierarchies stay on one rank (`ancestor_owner` for the finer levels):
+    bisection weighted by the work below each level-1 block (its own step + 2^(l-1) sub-steps of every level-l descendant
+    block per coarse step). Balance is limited by the level-1 block size; `level_owners` cuts every level on its own."""
+    c1 = np.asarray(grids[0].active_block_coords, dtype=np.int64)
+    lut = {tuple(c): i for i, c in enumerate(c1)}
+    w = np.ones(len(c1), dtype=np.float64)
+    for g in grids[1:]:
+        anc = ((np.asarray(g.active_block_coords, dtype=np.int64).reshape(-1, 3) - 1) >> (g.level_id - 1)) + 1
+        np.add.at(w, [lut[tuple(a)] for a in anc], float(2 ** (g.level_id - 1)))
+    return bisect_owner(c1, w, world)
+
+
+def level_owners(grids: Sequence[BlockLevel], world: int) -> List[np.ndarray]:
+    """Every level cut on its own into `world` parts of equal block count (planar cuts at that level's block size). The
+    levels are stepped one after the other with an exchange in between, so it is each level's balance that counts; the
+    cuts of different levels need not line up - a fine block's parent may live on another rank (see required_parent_blocks)."""
+    return [bisect_owner(g.active_block_coords, np.ones(g.n_blocks), world) for g in grids]
+
+
+def required_parent_blocks(child: BlockLevel, child_owned: np.ndarray, parent: BlockLevel) -> np.ndarray:
+    """Global ids (0-based) of the parent-level blocks the interface interpolation of the given owned child blocks can
+    touch: for every owned child block with a missing neighbour, its parent block and that block's 26 neighbours (the 8
+    stencil corners of a source cell just outside the child block lie within one parent cell of its parent's box)."""
+    nt = np.asarray(child.neighbor_table)[child_owned]
+    edge = child_owned[(nt == 0).any(axis=1)]
+    if edge.size == 0:
+        return np.zeros(0, dtype=np.int64)
+    cc = np.asarray(child.active_block_coords, dtype=np.int64).reshape(-1, 3)[edge]
+    pc = (cc + 1) // 2
+    pptr = np.asarray(parent.block_pointer)
+    inside = (pc >= 1).all(axis=1) & (pc[:, 0] <= pptr.shape[0]) & (pc[:, 1] <= pptr.shape[1]) & (pc[:, 2] <= pptr.shape[2])
+    pid = np.zeros(len(pc), dtype=np.int64)
+    pid[inside] = pptr[pc[inside, 0] - 1, pc[inside, 1] - 1, pc[inside, 2] - 1]
+    pid = np.unique(pid[pid > 0]) - 1
+    nb = np.asarray(parent.neighbor_table)[pid].reshape(-1)
+    return np.unique(np.concatenate([pid, nb[nb > 0] - 1]))
 
 
 def interpolation_needs(child: LocalView, parent: LocalView, domain_cells: Tuple[int, int, int]) -> Dict[str, np.ndarray]:
@@ -583,9 +620,12 @@ def interpolation_needs(child: LocalView, parent: LocalView, domain_cells: Tuple
 class MultiLevelRunner:
     """Distributed recursive_step! (src/solver_control.jl:21-143) for nested levels: same call order and A/B parity as
     the single-device driver, plus after every level step the halo exchange of that level (same-level ghosts AND the
-    parent-data ghosts its children interpolate from). Levels are small here, so the exchange is not overlapped."""
+    parent-data ghosts its children interpolate from). Levels are small here, so the exchange is not overlapped.
 
-    def __init__(self, grids: Sequence[BlockLevel], owner_level1: np.ndarray, params, rank: int, world: int, device: int,
+    owners: one owner array per level (`level_owners`: every level cut on its own, the default of DistributedStepper), or a
+    single level-1 array (whole hierarchies per rank: `balanced_owner` + `ancestor_owner`)."""
+
+    def __init__(self, grids: Sequence[BlockLevel], owners, params, rank: int, world: int, device: int,
                  stage_through_host: bool = False):
         import ctypes as C
         import torch
@@ -594,22 +634,33 @@ class MultiLevelRunner:
         self.params, self.rank, self.world = params, rank, world
         self.torch, self._lib = torch, _lib
         dims = (params.domain_nx, params.domain_ny, params.domain_nz)
-        self.views: List[LocalView] = []
-        for g in grids:
-            own = owner_level1 if g.level_id == 1 else ancestor_owner(g.level_id, g.active_block_coords, grids[0].active_block_coords, owner_level1)
-            v = build_local_level(g.level_id, g.active_block_coords, g.neighbor_table, own, rank, float(g.tau), temporal=g.f_old.size > 27)
+        if isinstance(owners, np.ndarray):
+            owner1 = owners
+            owners = [owner1] + [ancestor_owner(g.level_id, g.active_block_coords, grids[0].active_block_coords, owner1) for g in grids[1:]]
+        assert len(owners) == len(grids)
+        # finest first: a level's ghost set includes the parent blocks this rank's finer blocks interpolate from
+        views: List[Optional[LocalView]] = [None] * len(grids)
+        for i in range(len(grids) - 1, -1, -1):
+            g = grids[i]
+            extra = None
+            if i + 1 < len(grids):
+                child_owned = np.flatnonzero(np.asarray(owners[i + 1]) == rank)
+                extra = required_parent_blocks(grids[i + 1], child_owned, g)
+            v = build_local_level(g.level_id, g.active_block_coords, g.neighbor_table, owners[i], rank, float(g.tau),
+                                  temporal=g.f_old.size > 27, extra_ghosts=extra)
             slice_level_fields(v, g)
-            self.views.append(v)
-        # a rank that owns nothing of a (fine) level keeps no device level for it and skips it in the recursion
-        self.levels = [adapt(v.level, device) if v.n_owned > 0 else None for v in self.views]
+            views[i] = v
+        self.views = views
+        # no local copy at all of a level: None (skipped); only ghost copies (parent data for finer blocks): kept, never stepped
+        self.levels = [adapt(v.level, device) if v.level.n_blocks > 0 else None for v in self.views]
         self.dev = torch.device("cuda", device)
         lib = _lib.load()
         self.ex: List[HaloExchanger] = []
         for i, (v, g) in enumerate(zip(self.views, grids)):
-            needs = compute_needs(v)
+            needs = compute_needs(v) if v.n_owned > 0 else {"f": np.zeros(0, np.int64), "vel": np.zeros(0, np.int64)}
             needs.setdefault("f_post", np.zeros(0, np.int64))
             needs.setdefault("rho", np.zeros(0, np.int64))
-            if i + 1 < len(grids):
+            if i + 1 < len(grids) and self.views[i + 1].n_owned > 0:
                 extra = interpolation_needs(self.views[i + 1], v, dims)
                 for name in ("f", "rho", "vel"):
                     needs[name] = np.unique(np.concatenate([needs[name], extra[name]]))
@@ -632,11 +683,13 @@ class MultiLevelRunner:
         from .physics import apply_bouzidi_correction, stream_collide
         _lib = self._lib
         L, ex = self.levels[i], self.ex[i]
+        stepping = self.views[i].n_owned > 0                 # else: only ghost copies here, refreshed by the exchange below
         out_f, out_v = ("f_temp", "vel_temp") if t_sub % 2 == 0 else ("f", "vel")
-        stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
-        if L.has_post_collision:
-            if ex.plan.has("f_post"):
-                ex.exchange_post_collision()
+        if stepping:
+            stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
+        if ex.plan.has("f_post"):
+            ex.exchange_post_collision()
+        if stepping and L.has_post_collision:
             apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
         fields = {"f": out_f, "vel": out_v}
         if ex.plan.has("rho"):
@@ -644,16 +697,19 @@ class MultiLevelRunner:
         ex.exchange_fields(fields)
 
     def _rec(self, lvl: int, t_sub: int, parent, parent_tau, tw, u) -> None:
-        if lvl > len(self.levels) or self.levels[lvl - 1] is None:
+        if lvl > len(self.levels):
             return
         L = self.levels[lvl - 1]
-        has_children = lvl < len(self.levels) and self.levels[lvl] is not None
-        if has_children and self.params.use_temporal_interp and L.has_temporal_storage:
-            L.copy_to_old(t_sub)
-        self._step_level(lvl - 1, t_sub, parent, parent_tau, tw, u)
+        has_children = lvl < len(self.levels)
+        if L is not None:
+            if has_children and self.params.use_temporal_interp and L.has_temporal_storage:
+                L.copy_to_old(t_sub)
+            self._step_level(lvl - 1, t_sub, parent, parent_tau, tw, u)
         if has_children:
-            self._rec(lvl + 1, 2 * t_sub, L, L.tau, np.float32(0.0), u)
-            self._rec(lvl + 1, 2 * t_sub + 1, L, L.tau, np.float32(0.5), u)
+            # the level's tau is a property of the level, known on every rank (also where it has no copy of it)
+            tau = np.float32(self.views[lvl - 1].level.tau)
+            self._rec(lvl + 1, 2 * t_sub, L, tau, np.float32(0.0), u)
+            self._rec(lvl + 1, 2 * t_sub + 1, L, tau, np.float32(0.5), u)
 
     def step(self, t: int, u_curr=0.0) -> None:
         """one coarse step = recursive_step!(grids, 1, t, ...)"""

@@ -23,7 +23,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     from open_ludwig_amd import cases, partition
     from open_ludwig_amd.physics import SolverParams
-    grid = partition.rank_grid(world)
+    grid = partition.rank_grid(world) if world & (world - 1) == 0 else None      # bricks: power-of-two worlds only
     nbg = (nbx, nby, nbz)
     fn, vn = ("f_temp", "vel_temp") if steps % 2 == 0 else ("f", "vel")
     if mode == "cpu":
@@ -99,11 +99,18 @@ def main():
         return
     elif mode == "gpu_multilevel":
         # nested levels (interface interpolation from parent-data ghosts, temporal blend, Bouzidi sphere), split along x
-        levels, wall = overlap & 7, bool(overlap & 8)
+        levels, wall, per_level = overlap & 7, bool(overlap & 8), bool(overlap & 16)
         grids, params = cases.tunnel_with_sphere(nbg, levels=levels, wall_model=wall, temporal=True)
-        bx = np.asarray(grids[0].active_block_coords)[:, 0]
-        owner1 = ((bx - 1) * world // nbx).astype(np.int64)
-        runner = partition.MultiLevelRunner(grids, owner1, params, rank, world, device=0, stage_through_host=True)
+        if overlap & 32:   # staggered: level 1 entirely on rank 0, the finest level entirely on the last rank, the rest bisected
+            owners = partition.level_owners(grids, world)
+            owners[0] = np.zeros(grids[0].n_blocks, dtype=np.int64)
+            owners[-1] = np.full(grids[-1].n_blocks, world - 1, dtype=np.int64)
+        elif per_level:    # every level cut on its own: a fine block's parent may live on another rank
+            owners = partition.level_owners(grids, world)
+        else:              # x slabs of level-1 blocks, whole hierarchies per rank
+            bx = np.asarray(grids[0].active_block_coords)[:, 0]
+            owners = ((bx - 1) * world // nbx).astype(np.int64)
+        runner = partition.MultiLevelRunner(grids, owners, params, rank, world, device=0, stage_through_host=True)
         for t in range(1, steps + 1):
             runner.step(t, np.float32(0.05))
         runner.synchronize()
@@ -112,9 +119,9 @@ def main():
         for i, (lv, v) in enumerate(zip(runner.levels, runner.views)):
             f_name, v_name = _o.newest_buffers(i, steps)
             res[f"l2g{i}"] = v.local_to_global[: v.n_owned]
-            if lv is None:
+            if lv is None or v.n_owned == 0:
                 res[f"f{i}"], res[f"vel{i}"], res[f"rho{i}"] = np.zeros((8, 8, 8, 0, 27), np.float32), np.zeros((8, 8, 8, 0, 3), np.float32), np.zeros((8, 8, 8, 0), np.float32)
-                res[f"stats{i}"] = np.array([0, 0, 0, 0])
+                res[f"stats{i}"] = np.array([0, v.level.n_blocks, 0, 0])
                 continue
             res[f"f{i}"] = lv.download(f_name)[:, :, :, : v.n_owned]
             res[f"vel{i}"] = lv.download(v_name)[:, :, :, : v.n_owned]

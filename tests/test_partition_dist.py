@@ -121,6 +121,35 @@ def test_two_ranks_nested_levels_cut_through_the_refinement(tmp_path, gpu, level
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_nested_levels_every_level_cut_on_its_own(tmp_path, gpu, world):
+    """partition.level_owners: each of the 3 levels is bisected separately into `world` equal parts, so the cuts do not
+    line up and fine blocks interpolate from parent blocks that live on other ranks (kept as extra ghost copies; on some
+    ranks a level consists of such copies only). Owned blocks of every level must still equal the single-domain oracle
+    bit for bit, and every rank must own its share of every level."""
+    nbg, steps, levels = (8, 4, 4), 3, 3
+    _launch("gpu_multilevel", tmp_path, nbg, steps, world=world, overlap=levels | 16)
+    _check_multilevel(tmp_path, nbg, steps, levels, False, world)
+    grids, _ = cases.tunnel_with_sphere(nbg, levels=levels, wall_model=False, temporal=True)
+    for i, g in enumerate(grids):
+        owned = [int(np.load(os.path.join(tmp_path, f"rank{r}.npz"))[f"l2g{i}"].size) for r in range(world)]
+        assert sum(owned) == g.n_blocks and min(owned) >= 0.6 * g.n_blocks / world, (i + 1, owned)
+
+
+@pytest.mark.gpu
+def test_nested_levels_with_levels_living_on_single_ranks(tmp_path, gpu):
+    """Level 1 entirely on rank 0, level 3 entirely on rank 1, level 2 bisected: rank 1 holds level 1 only as ghost copies
+    (parent data for its level-2 blocks; n_owned < 0 in the ABI: nothing to step, halo unpack only), rank 0 has no copy of
+    level 3 at all. Still bit-identical to the single-domain oracle."""
+    nbg, steps, levels = (8, 4, 4), 3, 3
+    _launch("gpu_multilevel", tmp_path, nbg, steps, world=2, overlap=levels | 32)
+    _check_multilevel(tmp_path, nbg, steps, levels, False, 2)
+    d0, d1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
+    assert d1["l2g0"].size == 0 and d0["l2g2"].size == 0 and d0["l2g1"].size > 0 and d1["l2g1"].size > 0
+    assert d1["stats0"][1] > 0, "rank 1 keeps ghost copies of level 1"
+
+
+@pytest.mark.gpu
 def test_four_ranks_nested_levels_with_wall_model(tmp_path, gpu):
     nbg, steps = (8, 4, 4), 2
     _launch("gpu_multilevel", tmp_path, nbg, steps, world=4, overlap=2 | 8)
