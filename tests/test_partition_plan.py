@@ -167,3 +167,35 @@ def test_balanced_owner_cuts_nested_levels_by_work(world):
         c = c1[owner1 == r]
         lo, hi = c.min(axis=0), c.max(axis=0)
         assert len(c) == np.prod(hi - lo + 1)
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_parent_ghosts_cover_every_interpolation_stencil(world):
+    """Per-level cuts (level_owners): a rank keeps ghost copies of the parent blocks required_parent_blocks lists. They must
+    hold every parent cell the interface rule reads: the needs computed against that local parent level equal (as GLOBAL
+    elements) the needs computed against a parent level that has ALL remote parent blocks as ghosts."""
+    from open_ludwig_amd import cases
+    grids, params = cases.tunnel_with_sphere((8, 4, 4), levels=3, wall_model=False, temporal=True)
+    dims = (params.domain_nx, params.domain_ny, params.domain_nz)
+    owners = partition.level_owners(grids, world)
+    for o, g in zip(owners, grids):
+        counts = np.bincount(o, minlength=world)
+        assert counts.sum() == g.n_blocks and counts.max() - counts.min() <= max(2, 0.2 * counts.mean()), counts
+    total = 0
+    for rank in range(world):
+        for i in (0, 1):                                   # parent level index; child = i + 1
+            gp, gc = grids[i], grids[i + 1]
+            child = partition.build_local_level(gc.level_id, gc.active_block_coords, gc.neighbor_table, owners[i + 1], rank, float(gc.tau), temporal=True)
+            extra = partition.required_parent_blocks(gc, np.flatnonzero(owners[i + 1] == rank), gp)
+            local = partition.build_local_level(gp.level_id, gp.active_block_coords, gp.neighbor_table, owners[i], rank, float(gp.tau), temporal=True, extra_ghosts=extra)
+            full = partition.build_local_level(gp.level_id, gp.active_block_coords, gp.neighbor_table, owners[i], rank, float(gp.tau), temporal=True,
+                                               extra_ghosts=np.arange(gp.n_blocks))
+            assert full.level.n_blocks == gp.n_blocks and local.level.n_blocks <= full.level.n_blocks
+            a = partition.interpolation_needs(child, local, dims)
+            b = partition.interpolation_needs(child, full, dims)
+            for name in ("f", "rho", "vel"):
+                ga = np.sort(partition._to_global(local, a[name], gp.n_blocks))
+                gb = np.sort(partition._to_global(full, b[name], gp.n_blocks))
+                assert np.array_equal(ga, gb), (rank, i, name, ga.size, gb.size)
+            total += a["f"].size
+    assert total > 0
