@@ -10,8 +10,13 @@ The reference is single-device (F2); this module has no reference counterpart. D
   * exchange = gather by index list -> one message per peer (RCCL send/recv, point-to-point over xGMI) -> scatter.
     No collective on the data path. Boundary blocks are stepped first, so the exchange overlaps the interior update.
 
-Pure-numpy planning (build_local_level, compute_needs, HaloPlan) is separate from transport (HaloExchanger) and from the
-GPU runner, so the N > 1 logic is covered by CPU tests over gloo.
+  * nested levels (row N3): every level is cut on its own into equal parts (level_owners); a rank's copy of a level also
+    holds ghost copies of the parent blocks its finer blocks interpolate from (required_parent_blocks), and the parent
+    cells of those interface stencils join the parent level's needs (interpolation_needs). MultiLevelRunner repeats the
+    reference's recursion with one exchange after every level step.
+
+Pure-numpy planning (build_local_level, compute_needs, interpolation_needs, HaloPlan) is separate from transport
+(HaloExchanger) and from the GPU runners, so the N > 1 logic is covered by CPU tests over gloo.
 """
 from __future__ import annotations
 
