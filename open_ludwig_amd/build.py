@@ -8,7 +8,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["ludwig_hip.hip"]
-DEPENDS = ["ludwig_hip.hip", "kernels.hpp", "lattice.hpp", os.path.join("..", "..", "include", "ludwig_hip.h")]
+DEPENDS = ["ludwig_hip.hip", "kernels.hpp", "lattice.hpp", "jl_math.h", os.path.join("..", "..", "include", "ludwig_hip.h")]
 OUT = os.path.join(CSRC, "libludwig_hip.so")
 
 # -ffp-contract=off: the reference's CPU path never fuses a*b+c; parity with it is bit-level (DESIGN.md "Numerics").

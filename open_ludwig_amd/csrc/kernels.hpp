@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "lattice.hpp"
+#include "jl_math.h"
 
 namespace lw {
 
@@ -66,9 +67,10 @@ __device__ __forceinline__ float jl_clamp(float x, float lo, float hi)
 {
     return x > hi ? hi : (x < lo ? lo : x);
 }
-// Base.^(::Float32, ::Float32) and Base.log(::Float32) evaluate in Float64 and round once.
-__device__ __forceinline__ float jl_pow(float x, float y) { return (float)exp2(log2((double)x) * (double)y); }
-__device__ __forceinline__ float jl_log(float x) { return (float)log((double)x); }
+// Base.^(::Float32, ::Float32) and Base.log(::Float32) evaluate in Float64 and round once. The double log2 / exp2 / log are
+// jl_math.h's (IEEE +,-,*,/ only), the same source the CPU oracle compiles: identical bits on both sides.
+__device__ __forceinline__ float jl_pow(float x, float y) { return lw_powf(x, y); }
+__device__ __forceinline__ float jl_log(float x) { return lw_logf(x); }
 
 // c * v for c in {-1,0,1} resolved at compile time; `first` says whether the running sum is empty
 template <int C>

@@ -686,8 +686,8 @@ void ludwig_level_destroy(LudwigLevel *L)
 
 int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
 {
+    if (out) *out = nullptr;
     if (!h || !out) return fail(LUDWIG_ERR_INVALID, "null argument");
-    *out = nullptr;
     if (h->n_blocks < 0 || h->level_id < 1 || h->level_id > 30) return fail(LUDWIG_ERR_INVALID, "bad n_blocks/level_id");
     if (h->n_blocks > 0 && (!h->neighbor_table || !h->map_x || !h->map_y || !h->map_z)) return fail(LUDWIG_ERR_INVALID, "neighbor_table and map_x/y/z are required");
     if ((int64_t)h->n_blocks * CELLS * 4 >= (int64_t)1 << 32) return fail(LUDWIG_ERR_INVALID, "n_blocks too large for 32-bit byte offsets (max 2^21 - 1 blocks per level)");

@@ -15,6 +15,7 @@
  *   - n-ary + and * associate to the left        -> same as C
  */
 #include "ludwig_oracle.h"
+#include "../open_ludwig_amd/csrc/jl_math.h"
 
 #include <math.h>
 #include <string.h>
@@ -94,9 +95,20 @@ static inline float jl_clampf(float x, float lo, float hi)
 {
     return x > hi ? hi : (x < lo ? lo : x);
 }
-/* Base.^(::Float32,::Float32) widens, evaluates exp2(log2(x)*y) in Float64 and rounds once. */
-static inline float jl_powf(float x, float y) { return (float)exp2(log2((double)x) * (double)y); }
-static inline float jl_logf(float x)          { return (float)log((double)x); }
+/* Base.^(::Float32,::Float32) widens, evaluates exp2(log2(x)*y) in Float64 and rounds once; Base.log(::Float32) is a Float64
+ * kernel rounded once. The double log2 / exp2 / log come from the header the HIP kernels compile too (jl_math.h): the one
+ * piece of arithmetic the oracle shares with the product, so that wall-model cells are bit-comparable. It is itself
+ * checked against glibc in tests/test_jl_math.py through the two hooks below. */
+static inline float jl_powf(float x, float y) { return lw_powf(x, y); }
+static inline float jl_logf(float x)          { return lw_logf(x); }
+void oracle_jl_math(int which, const double *x, double *out, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? lw_log2(x[i]) : which == 1 ? lw_exp2(x[i]) : lw_log(x[i]);
+}
+void oracle_jl_powf(const float *x, const float *y, float *out, int64_t n)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = lw_powf(x[i], y[i]);
+}
 static inline float jl_cosf(float x)          { return (float)cos((double)x); }
 
 /* Float16 -> Float32, used at src/bouzidi_kernel.jl:36 */

@@ -48,8 +48,9 @@ class OracleParams(C.Structure):
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
-    src = os.path.join(_HERE, "ludwig_oracle.c")
-    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "ludwig_oracle.c"), os.path.join(_HERE, "ludwig_oracle.h"),
+            os.path.join(_HERE, "..", "open_ludwig_amd", "csrc", "jl_math.h")]
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True, capture_output=True)
     return LIB_PATH
 

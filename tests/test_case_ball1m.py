@@ -72,7 +72,8 @@ def test_hip_reproduces_reference_cd_series(gpu, ball_setup):
 
 @pytest.mark.gpu
 def test_hip_matches_oracle_on_ball1m(gpu, ball_setup):
-    """Same case, 200 coarse steps (952 M cell updates), HIP vs CPU oracle: Cd, Cl, rho_min within 1e-5 relative."""
+    """Same case, 200 coarse steps (952 M cell updates), HIP vs CPU oracle: Cd, Cl, rho_min identical (the wall model's
+    pow / log are the shared jl_math.h on both sides; the surface integration is the same host code)."""
     from _steppers import OracleStepper
     from oracle import oracle
     oracle.set_num_threads(16)
@@ -81,10 +82,9 @@ def test_hip_matches_oracle_on_ball1m(gpu, ball_setup):
     hip, _, _ = case.run_case(cfg, case.HipStepper, steps=200, setup=pp.setup_multilevel_domain(cfg, stl))
     ora, _, _ = case.run_case(cfg, OracleStepper, steps=200, setup=pp.setup_multilevel_domain(cfg, stl))
     assert len(hip) == len(ora) == 1 and hip[0].step == 200
-    for name in ("cd", "rho_min"):
+    for name in ("cd", "cl", "rho_min"):
         a, b = getattr(hip[0], name), getattr(ora[0], name)
-        assert abs(a - b) <= 1e-5 * abs(b), (name, a, b)
-    assert abs(hip[0].cl - ora[0].cl) <= 1e-5 * abs(ora[0].cd)      # Cl ~ 0 here: scale by Cd
+        assert a == b, (name, a, b)
 
 
 # ---- BASELINE configs[0]: cube1m as a single-level ~64^3 case, "BGK only" (c_wale = 0, nu_sgs_background = 0) ----
@@ -292,8 +292,7 @@ def test_device_stress_mapping_equals_host_mapping(gpu, ball_setup):
 @pytest.mark.gpu
 def test_hip_matches_oracle_on_ball1m_re10m(gpu, ball_re10m_setup):
     """The 4-level case (tau_fine 0.500001, sponge reaching level 2, 28 400 Bouzidi cells, wall model): 48 coarse steps
-    (980 M cell updates) on HIP and on the CPU oracle; every level's rho / vel within the north_star's 1e-5 relative (the
-    only non-identical arithmetic is the wall model's pow / log), Cd within 1e-5."""
+    (980 M cell updates) on HIP and on the CPU oracle; every level's rho / vel / f and the Cd row identical."""
     import copy
     from _steppers import OracleStepper
     from oracle import oracle
@@ -313,12 +312,11 @@ def test_hip_matches_oracle_on_ball1m_re10m(gpu, ball_re10m_setup):
     hip, _, _ = case.run_case(cfg, hip_factory, steps=steps, setup=setup_h)
     ora, _, _ = case.run_case(cfg, OracleStepper, steps=steps, setup=setup_o)
     assert len(hip) == len(ora) == 1
-    assert abs(hip[0].cd - ora[0].cd) <= 1e-5 * abs(ora[0].cd) and abs(hip[0].rho_min - ora[0].rho_min) <= 1e-6
+    assert hip[0].cd == ora[0].cd and hip[0].rho_min == ora[0].rho_min
     for i, g in enumerate(setup_o[0]):
         fn, vn = oracle.newest_buffers(i, steps)
         for name in ("rho", vn, fn):
             a, b = keep["st"].dev[i].download(name), getattr(g, name)
-            err = np.abs(a.astype(np.float64) - b).max() / np.abs(b).max()
-            assert err <= 1e-5, (i + 1, name, err)
+            assert np.array_equal(a, b), (i + 1, name, int(np.count_nonzero(a != b)))
     for d in keep["st"].dev:
         d.close()

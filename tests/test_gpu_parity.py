@@ -1,9 +1,9 @@
 """HIP path vs CPU oracle on identical inputs, through the C ABI (libludwig_hip.so).
 
 Bar (BASELINE.json north_star): rho/u within 1e-5 relative, FP32. What we actually assert is stronger: the HIP
-kernels keep the reference's operation order with contraction off, so every field is BIT-IDENTICAL to the oracle;
-the only exception is the wall-model force, whose pow/log come from a different libm (ocml vs glibc), where the
-1e-5 relative bound is asserted instead.
+kernels keep the reference's operation order with contraction off, so every field is BIT-IDENTICAL to the oracle -
+including the wall-model force since round 2: its pow / log are open_ludwig_amd/csrc/jl_math.h on both sides (the
+shared source is checked against glibc in tests/test_jl_math.py).
 """
 import numpy as np
 import pytest
@@ -121,7 +121,7 @@ def test_tunnel_interior_uses_x_runs(gpu, monkeypatch, merge):
     grids, params = cases.tunnel_with_sphere((8, 4, 4), levels=1, wall_model=True, tau=0.5003)
     dev = run_both(grids, params, 3, 0.05)
     assert dev[0].info().n_xrun_blocks >= 16
-    compare(grids, dev, 3, exact=False)
+    compare(grids, dev, 3)
 
 
 def test_periodic_box_bgk_only(gpu):
@@ -184,13 +184,13 @@ def test_tunnel_batches_match_single_batch(gpu):
 
 @pytest.mark.parametrize("levels", [1, 2])
 def test_tunnel_wall_model(gpu, levels):
-    """Wall-model force (pow/log): ocml vs glibc libm differ in the last ulp -> north_star tolerance 1e-5."""
+    """Wall-model force: x^(1/7) and log come from the shared jl_math.h on both sides -> bit-identical like the rest."""
     grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=levels, wall_model=True, tau=0.5003)
     near = sum(int(((g.wall_dist > 0) & (g.wall_dist < 10)).sum()) for g in grids)
     assert near > 1000
     steps = 3
     dev = run_both(grids, params, steps, 0.05)
-    compare(grids, dev, steps, exact=False)
+    compare(grids, dev, steps)
 
 
 def test_saved_old_state_survives_steps_without_a_new_save(gpu):

@@ -76,3 +76,77 @@ def test_product_package_never_imports_the_oracle():
                 code = re.sub(r'\"\"\".*?\"\"\"', "", code, flags=re.S)
                 m = bad.search(code)
                 assert m is None, (os.path.join(dirpath, f), m.group(0))
+
+
+# ---- the header as a C99 translation unit: struct layouts against the ctypes and Julia mirrors, calls through dlopen ----
+
+_JULIA_TYPES = {"Int32": (4, 4), "Float32": (4, 4), "Int64": (8, 8), "UInt8": (1, 1), "Int8": (1, 1)}   # name -> (size, align)
+
+
+def _julia_struct_layout(text, name):
+    """C layout of an immutable Julia struct of plain fields (Julia lays isbits structs out like C): [(field, offset, size)]"""
+    body = re.search(r"^struct\s+" + name + r"\b(.*?)^end", text, flags=re.S | re.M).group(1)
+    body = re.sub(r"#.*", "", body)
+    fields, off, max_al = [], 0, 1
+    for fname, ftype in re.findall(r"(\w+)::([\w{}]+)", body):
+        size, al = (8, 8) if ftype.startswith("Ptr{") else _JULIA_TYPES[ftype]
+        off = (off + al - 1) // al * al
+        fields.append((fname, off, size))
+        off += size
+        max_al = max(max_al, al)
+    return fields, (off + max_al - 1) // max_al * max_al
+
+
+@pytest.fixture(scope="module")
+def abi_report(tmp_path_factory):
+    build.build_library()
+    exe = str(tmp_path_factory.mktemp("abi") / "abi_check")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "abi_check.c"), "-o", exe, "-ldl"], check=True)
+    out = subprocess.run([exe, _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    rep = {"struct": {}, "field": {}, "enum": {}, "call": {}}
+    for line in out.splitlines():
+        kind, *rest = line.split(" ", 2)
+        if kind == "struct":
+            rep["struct"][rest[0]] = int(rest[1])
+        elif kind == "field":
+            sname, fname, o, sz = line.split()[1:]
+            rep["field"].setdefault(sname, []).append((fname, int(o), int(sz)))
+        elif kind == "enum":
+            rep["enum"][rest[0]] = int(rest[1])
+        elif kind == "call":
+            rep["call"][rest[0]] = rest[1] if len(rest) > 1 else ""
+    return rep
+
+
+def test_header_is_c99_and_struct_layouts_match_ctypes(abi_report):
+    pairs = {"LudwigLevelHost": _lib.LevelHost, "LudwigStepFlags": _lib.StepFlags, "LudwigSurfaceParams": _lib.SurfaceParams,
+             "LudwigLevelInfo": _lib.LevelInfo}
+    for cname, cls in pairs.items():
+        assert abi_report["struct"][cname] == C.sizeof(cls), cname
+        want = [(n, getattr(cls, n).offset, getattr(cls, n).size) for n, _ in cls._fields_]
+        assert abi_report["field"][cname] == want, cname          # same names, same order, same offsets and sizes
+    assert abi_report["enum"] == {"LUDWIG_FIELD_COUNT": len(_lib.FIELD_NAMES), "LUDWIG_WALL_DIST": _lib.WALL_DIST,
+                                  "LUDWIG_PART_INTERIOR": _lib.PART_INTERIOR}
+
+
+def test_julia_binding_structs_match_the_header(abi_report):
+    """julia/LudwigHIP.jl cannot run here (no Julia in the image); its struct definitions are at least layout-checked
+    against what gcc makes of the header, and every symbol it ccalls must be one the header declares."""
+    text = open(os.path.join(ROOT, "julia", "LudwigHIP.jl")).read()
+    for jname, cname in (("LevelHost", "LudwigLevelHost"), ("StepFlags", "LudwigStepFlags")):
+        fields, size = _julia_struct_layout(text, jname)
+        assert fields == abi_report["field"][cname], jname
+        assert size == abi_report["struct"][cname], jname
+    called = set(re.findall(r"ccall\(\(:(\w+), LIB\)", text))
+    assert called and called <= set(_header_functions()), called - set(_header_functions())
+    enum_line = re.search(r"const F, F_TEMP.*?= Int32\.\(0:(\d+)\)", text)
+    assert int(enum_line.group(1)) + 1 == abi_report["enum"]["LUDWIG_FIELD_COUNT"]
+
+
+def test_c_caller_through_dlopen(abi_report):
+    c = abi_report["call"]
+    assert c["abi_version"] == "1 1"
+    assert c["level_create_null"] == "-1 out_cleared"
+    assert "null" in c["last_error"]
+    assert c["level_create_bad"] == "-1" and c["level_info_null"] == "-1"

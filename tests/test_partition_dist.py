@@ -153,4 +153,4 @@ def test_nested_levels_with_levels_living_on_single_ranks(tmp_path, gpu):
 def test_four_ranks_nested_levels_with_wall_model(tmp_path, gpu):
     nbg, steps = (8, 4, 4), 2
     _launch("gpu_multilevel", tmp_path, nbg, steps, world=4, overlap=2 | 8)
-    _check_multilevel(tmp_path, nbg, steps, 2, True, 4, rtol=1e-5)
+    _check_multilevel(tmp_path, nbg, steps, 2, True, 4)          # wall model: shared jl_math.h, identical too

@@ -210,6 +210,103 @@ static Sched sched_xmarch(int PY, int len, bool xcd_by_layer)
     return s;
 }
 
+
+// x-run workgroups (4 x-adjacent blocks, one plane each, like the product) with a configurable sweep:
+// groups (run, by, bz) are ordered with `fast` dimensions first; ty > 0 sweeps by in tiles of ty (bz fastest inside a tile row);
+// the 8 planes of a group go to 8 consecutive workgroups, plane (x - bz) mod 8 on XCD x.
+static Sched sched_xrun(const char *sweep, int ty, bool halo_y = true)
+{
+    char nm[160];
+    snprintf(nm, sizeof nm, "xrun 4x1, 1 plane per wave, rotated planes, sweep %s, y tile %d", sweep, ty);
+    Sched s{nm, 4, 1, {}};
+    const int NB = NBg;
+    struct G { int bx0, by, bz; };
+    std::vector<G> gs;
+    for (int bx0 = 0; bx0 < NB; bx0 += 4) for (int by = 0; by < NB; ++by) for (int bz = 0; bz < NB; ++bz) gs.push_back({bx0, by, bz});
+    auto key = [&](const G &g, char c) { return c == 'x' ? g.bx0 : c == 'y' ? (ty > 0 ? g.by % ty : g.by) : c == 'z' ? g.bz : /* 'Y' tile index */ (ty > 0 ? g.by / ty : 0); };
+    const std::string sw = sweep;      // fastest first, e.g. "zyxY" / "yzYx"
+    std::stable_sort(gs.begin(), gs.end(), [&](const G &a, const G &b) {
+        for (int i = (int)sw.size() - 1; i >= 0; --i) { const int ka = key(a, sw[i]), kb = key(b, sw[i]); if (ka != kb) return ka < kb; }
+        return false;
+    });
+    for (const G &g : gs)
+        for (int x = 0; x < 8; ++x) {
+            const int z = ((x - g.bz) % 8 + 8) % 8;
+            for (int w = 0; w < 4; ++w) {
+                int fl = F_C | F_B | F_T;
+                if (halo_y) fl |= F_S | F_N;
+                if (w == 0) fl |= F_W;
+                if (w == 3) fl |= F_E;
+                s.items.push_back(((bid(g.bx0 + w, g.by, g.bz) << 3) | z) | fl);
+            }
+        }
+    return s;
+}
+
+// workgroup = all 8 planes of ONE block (velocity planes shared inside the workgroup), blocks in memory order
+static Sched sched_block8()
+{
+    Sched s{"block per workgroup (8 waves = 8 planes), memory order", 8, 1, {}};
+    const int n = NBg * NBg * NBg;
+    for (int b = 0; b < n; ++b)
+        for (int z = 0; z < 8; ++z) {
+            int fl = F_C | F_W | F_E | F_S | F_N;
+            if (z == 0) fl |= F_B;
+            if (z == 7) fl |= F_T;
+            s.items.push_back(((b << 3) | z) | fl);
+        }
+    return s;
+}
+
+// 2 x-adjacent blocks x 8 planes = 16 waves, memory order of the pair's first block
+static Sched sched_pair16(int PX)
+{
+    char nm[96];
+    snprintf(nm, sizeof nm, "%d x-adjacent blocks x 8 planes per workgroup, bz fastest", PX);
+    Sched s{nm, PX * 8, 1, {}};
+    const int NB = NBg;
+    for (int bx0 = 0; bx0 < NB; bx0 += PX) for (int by = 0; by < NB; ++by) for (int bz = 0; bz < NB; ++bz)
+        for (int w = 0; w < PX; ++w)
+            for (int z = 0; z < 8; ++z) {
+                int fl = F_C | F_S | F_N;
+                if (z == 0) fl |= F_B;
+                if (z == 7) fl |= F_T;
+                if (w == 0) fl |= F_W;
+                if (w == PX - 1) fl |= F_E;
+                s.items.push_back(((bid(bx0 + w, by, bz) << 3) | z) | fl);
+            }
+    return s;
+}
+
+// z-march over one block with a STAGGERED, cyclic start plane (z0 = (wave + workgroup) % 8): at any instant the chip works on
+// all 8 plane indices (address bits 8..10) instead of marching through them in lockstep
+static Sched sched_zmarch_staggered(int PX, int PY)
+{
+    char nm[160];
+    snprintf(nm, sizeof nm, "zmarch %dx%d patch, staggered cyclic start, XCD = layer", PX, PY);
+    Sched s{nm, PX * PY, 8, {}};
+    const int NB = NBg, npx = NB / PX, npy = NB / PY;
+    for (int round = 0; round < NB / 8; ++round)
+        for (int i = 0; i < npx * npy; ++i)
+            for (int xcd = 0; xcd < 8; ++xcd) {
+                const int bz = round * 8 + xcd, ppx = i / npy, ppy = i % npy;
+                const int z0 = (i + xcd) % 8;                    // the whole patch marches together (LDS exchange per plane)
+                for (int wj = 0; wj < PY; ++wj)
+                    for (int wi = 0; wi < PX; ++wi)
+                        for (int it = 0; it < 8; ++it) {
+                            const int z = (z0 + it) % 8;
+                            int fl = F_T;
+                            if (it == 0 || z == 0) fl |= F_C | F_B;   // start, and the wrap 7 -> 0
+                            if (wi == 0) fl |= F_W;
+                            if (wi == PX - 1) fl |= F_E;
+                            if (wj == 0) fl |= F_S;
+                            if (wj == PY - 1) fl |= F_N;
+                            s.items.push_back(((bid(ppx * PX + wi, ppy * PY + wj, bz) << 3) | z) | fl);
+                        }
+            }
+    return s;
+}
+
 // natural: block order, 4 consecutive planes per workgroup, nothing shared
 static Sched sched_natural(int niter)
 {
@@ -242,23 +339,46 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
     std::vector<Sched> all;
-    all.push_back(sched_current());
-    all.push_back(sched_natural(1));
-    all.push_back(sched_natural(8));
-    all.push_back(sched_zmarch(4, 1, 1, true, false));
-    all.push_back(sched_zmarch(4, 2, 1, true, false));
-    all.push_back(sched_zmarch(4, 2, 1, true, true));
-    all.push_back(sched_zmarch(4, 2, 1, false, false));
-    all.push_back(sched_zmarch(4, 4, 1, true, false));
-    all.push_back(sched_zmarch(8, 2, 1, true, false));
-    all.push_back(sched_zmarch(2, 2, 1, true, false));
-    all.push_back(sched_zmarch(4, 2, 4, true, false));
-    all.push_back(sched_zmarch(4, 2, 4, false, false));
-    all.push_back(sched_xmarch(1, 32, true));
-    all.push_back(sched_xmarch(1, 16, true));
-    all.push_back(sched_xmarch(2, 32, true));
-    all.push_back(sched_xmarch(2, 16, true));
-    all.push_back(sched_xmarch(1, 32, false));
+    const char *sel = argc > 3 ? argv[3] : "2";
+    if (strchr(sel, '1')) {
+        all.push_back(sched_current());
+        all.push_back(sched_natural(1));
+        all.push_back(sched_natural(8));
+        all.push_back(sched_zmarch(4, 1, 1, true, false));
+        all.push_back(sched_zmarch(4, 2, 1, true, false));
+        all.push_back(sched_zmarch(4, 2, 1, true, true));
+        all.push_back(sched_zmarch(4, 2, 1, false, false));
+        all.push_back(sched_zmarch(4, 4, 1, true, false));
+        all.push_back(sched_zmarch(8, 2, 1, true, false));
+        all.push_back(sched_zmarch(2, 2, 1, true, false));
+        all.push_back(sched_zmarch(4, 2, 4, true, false));
+        all.push_back(sched_zmarch(4, 2, 4, false, false));
+        all.push_back(sched_xmarch(1, 32, true));
+        all.push_back(sched_xmarch(1, 16, true));
+        all.push_back(sched_xmarch(2, 32, true));
+        all.push_back(sched_xmarch(2, 16, true));
+        all.push_back(sched_xmarch(1, 32, false));
+    }
+    if (strchr(sel, '2')) {
+        all.push_back(sched_current());
+        all.push_back(sched_natural(1));
+        all.push_back(sched_xrun("yxz", 0));          // = cur
+        all.push_back(sched_xrun("zyx", 0));
+        all.push_back(sched_xrun("zxy", 0));
+        all.push_back(sched_xrun("xyz", 0));
+        all.push_back(sched_xrun("xzy", 0));
+        all.push_back(sched_xrun("yzx", 0));
+        all.push_back(sched_xrun("yzYx", 2));
+        all.push_back(sched_xrun("yzYx", 4));
+        all.push_back(sched_xrun("yzYx", 8));
+        all.push_back(sched_xrun("zyYx", 4));
+        all.push_back(sched_xrun("yzxY", 4));
+        all.push_back(sched_block8());
+        all.push_back(sched_pair16(2));
+        all.push_back(sched_zmarch_staggered(4, 1));
+        all.push_back(sched_zmarch_staggered(4, 2));
+        all.push_back(sched_current());
+    }
 
     printf("# NB = %d (%zu cells), %d reps each, median; 244 B/cell compulsory (27+3 in, 27+3+1 out)\n", NB, cells, reps);
     printf("# columns: ms without any halo / velocity-plane refetch (mask: only F_C)  |  ms with the design's global halo + plane fetches\n");
