@@ -47,6 +47,9 @@ struct SCParams {
     // level that needs one, precomputed densely by k_interface_links: f_iface[(k * n_iface_blocks + gbi) * 512 + cell]
     float *f_iface;
     int32_t n_iface_blocks;
+    // 0: this launch leaves `rho` unwritten - nobody reads it before the level's next step unless asked, and then
+    // k_stream_collide_xrun<.., RHO_ONLY> recomputes it from the same inputs (ludwig_hip.hip "lazy rho")
+    int32_t store_rho;
 };
 
 template <int K, int N, class F>
@@ -199,8 +202,20 @@ struct NeighbourIds {
 __device__ __forceinline__ NeighbourIds load_neighbour_ids(const int32_t *__restrict__ meta, int z)
 {
     int nb[27];
+#ifdef LW_DIAG_ARITH_NBR   // timing-only: neighbour ids of the 32^3 periodic box computed, not loaded (no dependent scalar load)
+    {
+        const int b0 = (int)(meta - (const int32_t *)nullptr) / NBR_STRIDE;   // caller passes meta = nullptr + b * stride
+        const int bz = b0 & 31, by = (b0 >> 5) & 31, bx = b0 >> 10;
+#pragma unroll
+        for (int d = 0; d < 27; ++d) {
+            const int ox = d % 3 - 1, oy = (d / 3) % 3 - 1, oz = d / 9 - 1;
+            nb[d] = ((((bx + ox) & 31) << 5) | ((by + oy) & 31)) << 5 | ((bz + oz) & 31);
+        }
+    }
+#else
 #pragma unroll
     for (int d = 0; d < 27; ++d) nb[d] = meta[d];            // wave-uniform -> scalar loads, one burst
+#endif
     NeighbourIds n;
     const bool z_lo = z == 0, z_hi = z == 7;                 // wave-uniform
 #pragma unroll
@@ -316,7 +331,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
         st_f32(p.vel_out, own_bytes, 0.0f);
         st_f32(p.vel_out + p.sk, own_bytes, 0.0f);
         st_f32(p.vel_out + 2 * p.sk, own_bytes, 0.0f);
-        st_f32(p.rho, own_bytes, 1.0f);
+        if (p.store_rho) st_f32(p.rho, own_bytes, 1.0f);
         static_for<0, Q>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const float f_coll = fs[OPP(k)];
@@ -365,7 +380,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     st_f32(p.vel_out, own_bytes, ux);
     st_f32(p.vel_out + p.sk, own_bytes, uy);
     st_f32(p.vel_out + 2 * p.sk, own_bytes, uz);
-    st_f32(p.rho, own_bytes, rho);
+    if (p.store_rho) st_f32(p.rho, own_bytes, rho);
 
     // ---- WALE eddy viscosity from the previous step's velocity, reference :251-300 ----
     const float g11 = 0.5f * (ux_E - ux_W), g12 = 0.5f * (ux_N - ux_S), g13 = 0.5f * (ux_T - ux_B);
@@ -446,6 +461,24 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
         if constexpr (POST) { if (store_post) st_f32(p.f_post + p.sk * k, own_bytes, f_coll); }
         st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
     });
+}
+
+// The density finish_cell would have stored for this cell, and nothing else: the same sums in the same order (reference
+// src/physics_kernels.jl:144-148, :154-158 obstacle, :172 clamp, :181-186 sponge). Used to produce `rho` on demand after a
+// step that skipped the store.
+__device__ __forceinline__ void finish_rho_only(const SCParams &p, const int flags, const uint32_t own_bytes, const float (&fs)[Q])
+{
+    float rho = 0.0f;
+    static_for<0, Q>([&](auto kc) { rho += fs[decltype(kc)::value]; });
+    bool is_obs = false;
+    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own_bytes >> 2] != 0;
+    if (is_obs) { st_f32(p.rho, own_bytes, 1.0f); return; }
+    rho = jl_max(rho, 0.01f);
+    if (flags & FLAG_HAS_SPONGE) {
+        const float sp = ld_f32(p.sponge, own_bytes);
+        if (sp > 0.0f) rho = rho * (1.0f - sp) + 1.0f * sp;
+    }
+    st_f32(p.rho, own_bytes, rho);
 }
 
 // Lanes whose source block is missing: the domain-edge chain of reference src/physics_kernels.jl:88-140 (1-based global
@@ -571,7 +604,7 @@ constexpr int ITEM_LINK_W = 1 << 30;   // wave - 1 of this workgroup holds the -
 constexpr int ITEM_LINK_E = 1 << 29;   // wave + 1 holds the +x neighbour block, same plane
 constexpr int ITEM_ID_MASK = (1 << 29) - 1;
 
-template <int NW, bool GENERAL, bool POST, bool WALL>
+template <int NW, bool GENERAL, bool POST, bool WALL, bool RHO_ONLY = false>
 __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams p)
 {
     __shared__ float xch[NW][24][8];
@@ -585,8 +618,13 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     LanePos l;
     l.x = lane & 7; l.y = lane >> 3;
     l.x0 = l.x == 0; l.x7 = l.x == 7; l.y0 = l.y == 0; l.y7 = l.y == 7;
+#ifdef LW_DIAG_ARITH_NBR
+    const int32_t *__restrict__ meta = (const int32_t *)nullptr + (size_t)b * NBR_STRIDE;
+    const int flags = FLAG_ALL_NEIGHBOURS;
+#else
     const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
     const int flags = meta[NBR_FLAGS];
+#endif
     const NeighbourIds nbr = load_neighbour_ids(meta, z);
     const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
     // wave-uniform: a run may be shorter than the workgroup (several short runs, or single blocks, share one)
@@ -629,7 +667,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         }
     });
     // previous-step velocity: centre plane, planes z+-1 (aligned), y-face rows and outer x-face columns (masked)
-    {
+    if constexpr (!RHO_ONLY) {
         const int bT = z == 7 ? nbr.id[2][4] : b, bB = z == 0 ? nbr.id[0][4] : b;
         const uint32_t xy = (uint32_t)((l.x + 8 * l.y) * 4);
         uint32_t offT = (uint32_t)bT * (CELLS * 4) + xy + (uint32_t)(((z + 1) & 7) * 256);
@@ -671,40 +709,56 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     }
 
     // ---- publish the face columns the neighbouring waves need ----
+#ifndef LW_DIAG_NO_XCH
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int cx = CX(k);
         if constexpr (cx == 1) { if (l.x7) xch[wave][XSLOT(k)][l.y] = fs[k]; }
         if constexpr (cx == -1) { if (l.x0) xch[wave][XSLOT(k)][l.y] = fs[k]; }
     });
+    if constexpr (!RHO_ONLY) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (l.x7) xch[wave][18 + c][l.y] = uc[c];
-        if (l.x0) xch[wave][21 + c][l.y] = uc[c];
+        for (int c = 0; c < 3; ++c) {
+            if (l.x7) xch[wave][18 + c][l.y] = uc[c];
+            if (l.x0) xch[wave][21 + c][l.y] = uc[c];
+        }
     }
+#endif
     }   // if (active)
+#ifndef LW_DIAG_NO_XCH
     __syncthreads();
+#endif
     if (!active) return;
+#ifdef LW_DIAG_NO_XCH   // timing-only: no LDS traffic at all
+#define LW_XCH(w, s, y) 0.0f
+#else
+#define LW_XCH(w, s, y) xch[w][s][y]
+#endif
     const int wlo = first ? 0 : wave - 1, whi = last ? NW - 1 : wave + 1;
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int cx = CX(k);
         if constexpr (cx == 1) {
             const float inner = dpp_from_lower_lane(fs[k]);
-            const float edge = first ? halo[k] : xch[wlo][XSLOT(k)][l.y];
+            const float edge = first ? halo[k] : LW_XCH(wlo, XSLOT(k), l.y);
             fs[k] = l.x0 ? edge : inner;
         }
         if constexpr (cx == -1) {
             const float inner = dpp_from_upper_lane(fs[k]);
-            const float edge = last ? halo[k] : xch[whi][XSLOT(k)][l.y];
+            const float edge = last ? halo[k] : LW_XCH(whi, XSLOT(k), l.y);
             fs[k] = l.x7 ? edge : inner;
         }
     });
+    if constexpr (RHO_ONLY) {
+        if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, b, z, own_bytes, fs);
+        finish_rho_only(p, flags, own_bytes, fs);
+        return;
+    }
     float uE[3], uW[3], uN[3], uS[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float e_edge = last ? ux_edge_hi[c] : xch[whi][21 + c][l.y];
-        const float w_edge = first ? ux_edge_lo[c] : xch[wlo][18 + c][l.y];
+        const float e_edge = last ? ux_edge_hi[c] : LW_XCH(whi, 21 + c, l.y);
+        const float w_edge = first ? ux_edge_lo[c] : LW_XCH(wlo, 18 + c, l.y);
         // cross-lane reads must execute with ALL lanes active: never inside an arm of ?: (that arm runs under a
         // reduced EXEC mask and a DPP read of an inactive lane silently keeps the old value)
         const float e_in = dpp_from_upper_lane(uc[c]), w_in = dpp_from_lower_lane(uc[c]);

@@ -95,6 +95,18 @@ struct LudwigLevel {
         float tw = 0.0f, tau_parent = 0.0f;
         int use_temporal = 0;
     } ahead[N_PARTS];
+    // Lazy rho. The step writes `rho` (4 of 244 B per cell update) for readers that mostly are not there: the next step
+    // overwrites it unread unless a child level interpolates from it (every step), or a diagnostic / download / save asks
+    // for it (now and then). A level nobody has read `rho` of in between therefore skips the store and remembers the
+    // launch (rho_replay); ensure_rho() reproduces the array on demand with the RHO_ONLY instantiation, from the same
+    // input buffers (a pull step never writes its inputs) - bit for bit what the step would have stored.
+    bool rho_eager = false;             // a child reads rho after every step (or LUDWIG_EAGER_RHO): always store
+    struct RhoReplay {
+        bool stale = false;             // the launch of this part left rho unwritten
+        bool lost = false;              // ... and a later launch of ANOTHER part has since overwritten its input buffer
+        int64_t t_sub = -1;
+        SCParams p;
+    } rho_replay[N_PARTS];
     uint64_t version = 0;               // bumped by everything that writes this level's fields
     const LudwigLevel *iface_parent = nullptr;
     std::vector<int32_t> h_block_pointer;   // [gdx,gdy,gdz] 1-based, 0 = absent (src/blocks.jl:111-114)
@@ -129,6 +141,8 @@ struct FieldDesc {
     size_t bytes;
 };
 
+int ensure_rho(LudwigLevel *L);
+
 int materialize_old(LudwigLevel *L)
 {
     if (L->old_alias < 0) return LUDWIG_OK;
@@ -145,6 +159,15 @@ int materialize_old(LudwigLevel *L)
 // call before anything but a stream-collide step writes `field` (upload, halo unpack, a raw pointer handed out)
 int before_external_write(LudwigLevel *L, int field)
 {
+    // an elided rho is recomputed from the input populations / sponge / obstacle of the last step: produce it before any
+    // of them changes (a halo unpack into the OUTPUT buffer of that step, the usual case, does not touch them)
+    bool feeds_rho = field == LUDWIG_SPONGE || field == LUDWIG_OBSTACLE || field == LUDWIG_RHO;
+    for (int a = 0; a < N_PARTS; ++a)
+        if (L->rho_replay[a].stale && (field == LUDWIG_F || field == LUDWIG_F_TEMP) && L->f[field == LUDWIG_F ? 0 : 1] == L->rho_replay[a].p.f_in) feeds_rho = true;
+    if (feeds_rho) {
+        const int r = ensure_rho(L);
+        if (r) return r;
+    }
     if (L->old_alias < 0) return LUDWIG_OK;
     const int a = L->old_alias;
     const bool hits = field == LUDWIG_F_OLD || field == LUDWIG_VEL_OLD || (field == LUDWIG_F && a == 0) || (field == LUDWIG_F_TEMP && a == 1) ||
@@ -549,6 +572,33 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     p.use_temporal = (fl->use_temporal_interp && (!parent || parent->has_temporal)) ? 1 : 0;
     p.sponge_blend = fl->sponge_blend_distributions ? 1 : 0;
 
+    // lazy rho: who reads rho before this level's next step?
+    if (parent && !parent->rho_eager) {            // a child interpolates from its parent's rho after every parent step
+        LudwigLevel *pm = const_cast<LudwigLevel *>(parent);
+        pm->rho_eager = true;
+        const int r = ensure_rho(pm);
+        if (r) return r;
+    }
+    {
+        static const bool eager_env = getenv("LUDWIG_EAGER_RHO") != nullptr || getenv("LUDWIG_NO_XRUN") != nullptr;
+        const bool store = L->rho_eager || eager_env;
+        // whole-level launches and part launches do not mix in one bookkeeping: settle the other kind first
+        if (part != LUDWIG_PART_ALL && L->rho_replay[LUDWIG_PART_ALL].stale) {
+            const int r = ensure_rho(L);
+            if (r) return r;
+        }
+        // This launch reuses the previous step's INPUT buffer as its output. An elided rho of the cells it covers is simply
+        // superseded (the reference would be overwriting it right now, unread); an elided rho of another part can no longer
+        // be produced once its inputs are gone: it is marked lost, and asking for it is an error instead of a wrong answer.
+        for (int a = 0; a < N_PARTS; ++a) {
+            LudwigLevel::RhoReplay &rr = L->rho_replay[a];
+            if (!rr.stale) continue;
+            if (a == part || part == LUDWIG_PART_ALL) rr.stale = rr.lost = false;
+            else if (rr.t_sub != t_sub) rr.lost = true;
+        }
+        p.store_rho = store ? 1 : 0;
+    }
+
     const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
     if (parent && L->n_items[part][1] > 0) {
         // coarse -> fine interface pass for the general blocks of this part (reference src/physics_kernels.jl:122-137)
@@ -611,6 +661,47 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
 #undef LW_LAUNCH_X
 #undef LW_LAUNCH
         LW_HIP(hipGetLastError());
+    }
+    if (!p.store_rho) {
+        LudwigLevel::RhoReplay &rr = L->rho_replay[part];
+        rr.stale = true;
+        rr.lost = false;
+        rr.t_sub = t_sub;
+        rr.p = p;                                    // pointers into this level's (and the parent's) buffers, scalars of the step
+    }
+    return LUDWIG_OK;
+}
+
+// Produce `rho` now if the last step left it unwritten (see LudwigLevel::rho_replay).
+int ensure_rho(LudwigLevel *L)
+{
+    bool any = false;
+    for (int a = 0; a < N_PARTS; ++a) any = any || L->rho_replay[a].stale;
+    if (!any) return LUDWIG_OK;
+    LW_HIP(hipSetDevice(L->device));
+    for (int part = 0; part < N_PARTS; ++part) {
+        LudwigLevel::RhoReplay &rr = L->rho_replay[part];
+        if (!rr.stale) continue;
+        if (rr.lost)
+            return fail(LUDWIG_ERR_STATE, "rho of part %d was left unwritten by step %lld and a later launch of another part has reused its inputs: "
+                        "read rho after a complete step, or set LUDWIG_EAGER_RHO=1", part, (long long)rr.t_sub);
+        SCParams p = rr.p;
+        p.store_rho = 1;
+        for (int c = 1; c < N_CLASSES; ++c) {
+            if (L->n_items[part][c] == 0) continue;
+            p.items = L->items[part][c];
+            const bool general = c == 1;
+            const dim3 g4((unsigned)(L->n_items[part][c] / 4)), g8((unsigned)(L->n_items[part][c] / 8));
+            if (XRUN == 8) {
+                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<8, true, false, false, true>), g8, dim3(512), 0, L->stream, p);
+                else hipLaunchKernelGGL((k_stream_collide_xrun<8, false, false, false, true>), g8, dim3(512), 0, L->stream, p);
+            } else {
+                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<4, true, false, false, true>), g4, dim3(256), 0, L->stream, p);
+                else hipLaunchKernelGGL((k_stream_collide_xrun<4, false, false, false, true>), g4, dim3(256), 0, L->stream, p);
+            }
+            LW_HIP(hipGetLastError());
+        }
+        rr.stale = false;
     }
     return LUDWIG_OK;
 }
@@ -907,6 +998,10 @@ int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t by
     if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
     if (bytes != d.bytes) return fail(LUDWIG_ERR_INVALID, "field %d: got %zu bytes, expected %zu", field, bytes, d.bytes);
     LW_HIP(hipSetDevice(L->device));
+    if (field == LUDWIG_RHO) {
+        const int r = ensure_rho(const_cast<LudwigLevel *>(L));
+        if (r) return r;
+    }
     LW_HIP(hipMemcpyAsync(host, d.ptr, bytes, hipMemcpyDeviceToHost, L->stream));
     LW_HIP(hipStreamSynchronize(L->stream));
     return LUDWIG_OK;
@@ -934,6 +1029,10 @@ int ludwig_init_equilibrium(LudwigLevel *L)
     LW_HIP(hipSetDevice(L->device));
     const unsigned grid = (unsigned)((L->sk + 255) / 256);
     ++L->version;
+    {
+        const int r = ensure_rho(L);                 // init_eq! leaves rho alone: it must hold what the last step made of it
+        if (r) return r;
+    }
     hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[0], L->sk);
     hipLaunchKernelGGL(k_fill_weights, dim3(grid), dim3(256), 0, L->stream, L->f[1], L->sk);
     if (L->has_temporal) {
@@ -973,6 +1072,11 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
     // f and vel: no copy - the step that follows reads f[in] / vel[in] and never writes them (see old_alias)
     ++L->version;
     L->old_alias = in;
+    L->rho_eager = true;                             // a level that saves its old state has children reading rho every step
+    {
+        const int r = ensure_rho(L);
+        if (r) return r;
+    }
     LW_HIP(hipMemcpyAsync(L->rho_old, L->rho, c * 4, hipMemcpyDeviceToDevice, L->stream));
     return LUDWIG_OK;
 }
@@ -1030,6 +1134,10 @@ int ludwig_map_surface_stresses(const LudwigLevel *L, int vel_field, int32_t n_t
         return fail(LUDWIG_ERR_STATE, "level has no blocks or was created without block_pointer");
     if (!(sp->dx > 0.0f) || sp->search_radius < 0 || sp->search_radius > 16) return fail(LUDWIG_ERR_INVALID, "bad dx or search radius");
     LW_HIP(hipSetDevice(L->device));
+    {
+        const int r = ensure_rho(const_cast<LudwigLevel *>(L));
+        if (r) return r;
+    }
     // scratch: [block_pointer | centers | normals | 4 outputs]; a diagnostics call every few hundred steps, so allocated per call
     const size_t nptr = L->h_block_pointer.size(), n = (size_t)n_tri;
     char *buf = nullptr;
@@ -1070,6 +1178,10 @@ int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, 
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be packed", field);
     LW_HIP(hipSetDevice(L->device));
+    if (field == LUDWIG_RHO) {
+        const int r = ensure_rho(const_cast<LudwigLevel *>(L));
+        if (r) return r;
+    }
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;

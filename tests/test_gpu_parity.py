@@ -270,3 +270,66 @@ def test_interface_values_computed_ahead_are_dropped_when_the_parent_changes(gpu
         for d in dev:
             d.close()
     assert np.array_equal(results[0][0], results[1][0]) and np.array_equal(results[0][1], results[1][1])
+
+
+# ---- lazy rho: the step leaves `rho` unwritten when nobody reads it before the next step, and reproduces it on demand ----
+
+def test_lazy_rho_is_what_the_step_would_have_stored(gpu, monkeypatch):
+    """Single level (no child reads rho): the stores are elided, a download replays them. Checked against the oracle after
+    1, 2 and 5 steps, with edge blocks, obstacle, sponge and Bouzidi in play, and against the eager library bit for bit."""
+    from open_ludwig_amd.physics import perform_timestep_v2
+    grids, params = cases.tunnel_with_sphere((6, 3, 3), levels=1, wall_model=True, tau=0.5003)
+    dev = [adapt(g, 0) for g in grids]
+    t = 1
+    for n in (1, 1, 3):
+        execute_timestep_batch(dev, t, n, np.float32(0.05), params)
+        oracle.execute_timestep_batch(grids, t, n, np.float32(0.05), params)
+        t += n
+        assert np.array_equal(dev[0].download("rho"), grids[0].rho), f"after step {t - 1}"
+    # an upload into the step's INPUT buffer must not change the answer: rho is produced before the upload lands
+    execute_timestep_batch(dev, t, 1, np.float32(0.05), params)
+    oracle.execute_timestep_batch(grids, t, 1, np.float32(0.05), params)
+    f_in_name = "f" if t % 2 == 0 else "f_temp"
+    dev[0].upload(f_in_name, np.zeros_like(grids[0].f))
+    assert np.array_equal(dev[0].download("rho"), grids[0].rho)
+    dev[0].close()
+    # the same run with the stores forced on
+    monkeypatch.setenv("LUDWIG_EAGER_RHO", "1")
+    import subprocess, sys, os
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from open_ludwig_amd import adapt, cases, execute_timestep_batch;"
+            "g, p = cases.tunnel_with_sphere((6, 3, 3), levels=1, wall_model=True, tau=0.5003); d = adapt(g[0], 0);"
+            "execute_timestep_batch([d], 1, 6, np.float32(0.05), p); np.save(sys.argv[1], d.download('rho'))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "rho.npy")
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=dict(os.environ, LUDWIG_EAGER_RHO="1"))
+        assert np.array_equal(np.load(out), grids[0].rho)
+
+
+def test_lazy_rho_across_part_launches(gpu):
+    """Multi-GPU style stepping (boundary part, then interior part): rho is reproducible after a complete step; between the
+    two part launches of the NEXT step the interior's elided rho is gone, and asking for it is an error, not a wrong answer."""
+    import ctypes as C
+    from open_ludwig_amd import _lib
+    lib = _lib.load()
+    grids, params = cases.periodic_box((4, 2, 2))
+    cases.init_perturbed(grids[0], 3)
+    g = grids[0]
+    g.comm_boundary = (np.asarray(g.map_x) == 1).astype(np.uint8)          # pretend the bx = 1 slab touches a peer
+    d = adapt(g, 0)
+    fl = params.to_c()
+    for t in (1, 2):
+        for part in (_lib.PART_BOUNDARY, _lib.PART_INTERIOR):
+            _lib.check(lib.ludwig_stream_collide(d.handle, None, t, 0.0, 0.5, 0.0, C.byref(fl), part))
+    oracle.execute_timestep_batch(grids, 1, 2, np.float32(0.0), params)
+    assert np.array_equal(d.download("rho"), g.rho)
+    for part in (_lib.PART_BOUNDARY, _lib.PART_INTERIOR):
+        _lib.check(lib.ludwig_stream_collide(d.handle, None, 3, 0.0, 0.5, 0.0, C.byref(fl), part))
+    _lib.check(lib.ludwig_stream_collide(d.handle, None, 4, 0.0, 0.5, 0.0, C.byref(fl), _lib.PART_BOUNDARY))
+    buf = np.empty_like(g.rho)
+    assert lib.ludwig_level_download(d.handle, _lib.RHO, buf.ctypes.data, buf.nbytes) == -5       # LUDWIG_ERR_STATE
+    assert b"LUDWIG_EAGER_RHO" in lib.ludwig_last_error()
+    _lib.check(lib.ludwig_stream_collide(d.handle, None, 4, 0.0, 0.5, 0.0, C.byref(fl), _lib.PART_INTERIOR))
+    oracle.execute_timestep_batch(grids, 3, 2, np.float32(0.0), params)
+    assert np.array_equal(d.download("rho"), g.rho)
+    d.close()

@@ -24,10 +24,11 @@ __device__ __forceinline__ int wrap(int v, int n) { return v < 0 ? v + n : (v >=
 __device__ __forceinline__ float ldf(const float *base, uint32_t off) { return *(const float *)((const char *)base + off); }
 __device__ __forceinline__ void stf(float *base, uint32_t off, float v) { __builtin_nontemporal_store(v, (float *)((char *)base + off)); }
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_march(const float *__restrict__ fin, float *__restrict__ fout, const float *__restrict__ vin,
-                                                   float *__restrict__ vout, float *__restrict__ rho, const int *__restrict__ items,
-                                                   int niter, size_t sk, int NB, int mask)
+template <int NW, bool DEP = false, int WPE = 0>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE == 0 ? 1 : WPE, WPE == 0 ? 8 : WPE)))
+void k_march(const float *__restrict__ fin, float *__restrict__ fout, const float *__restrict__ vin,
+             float *__restrict__ vout, float *__restrict__ rho, const int *__restrict__ items,
+             int niter, size_t sk, int NB, int mask, const int *__restrict__ meta = nullptr)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, x = lane & 7, y = lane >> 3;
@@ -39,7 +40,15 @@ __global__ __launch_bounds__(64 * NW) void k_march(const float *__restrict__ fin
         const int fl = raw & mask;
         const int id = raw & ID_MASK, b = id >> 3, z = id & 7;
         const int bz = b % NB, by = (b / NB) % NB, bx = b / (NB * NB);
-        auto blk = [&](int ox, int oy, int oz) { return (uint32_t)((wrap(bx + ox, NB) * NB + wrap(by + oy, NB)) * NB + wrap(bz + oz, NB)); };
+        int nbm[27];
+        if (DEP) {     // as the product: the 27 neighbour ids come from a per-block row, a scalar load that depends on the item
+#pragma unroll
+            for (int d = 0; d < 27; ++d) nbm[d] = meta[(size_t)b * 32 + d];
+        }
+        auto blk = [&](int ox, int oy, int oz) {
+            if (DEP) return (uint32_t)nbm[(ox + 1) + 3 * (oy + 1) + 9 * (oz + 1)];
+            return (uint32_t)((wrap(bx + ox, NB) * NB + wrap(by + oy, NB)) * NB + wrap(bz + oz, NB));
+        };
         float v[Q];
 #pragma unroll
         for (int k = 0; k < Q; ++k) {
@@ -109,6 +118,8 @@ struct Sched {
     std::string name;
     int nw, niter;
     std::vector<int> items;      // [wg][wave][iter]
+    int variant = 0;             // 0 plain, 1 dependent neighbour-id load, 2 capped at 5 waves per SIMD, 3 both
+    int halo_mask = ~0;          // which of the design's global fetches the "with halos" pass keeps
 };
 
 static int NBg = 32;
@@ -335,6 +346,17 @@ int main(int argc, char **argv)
     CK(hipMalloc(&fin, sk * Q * 4)); CK(hipMalloc(&fout, sk * Q * 4));
     CK(hipMalloc(&vin, sk * 3 * 4)); CK(hipMalloc(&vout, sk * 3 * 4)); CK(hipMalloc(&rho, sk * 4));
     CK(hipMemset(fin, 0, sk * Q * 4)); CK(hipMemset(vin, 0, sk * 3 * 4));
+    int *d_meta;
+    {
+        std::vector<int> m(nblk * 32, 0);
+        for (int bx = 0; bx < NB; ++bx) for (int by = 0; by < NB; ++by) for (int bz = 0; bz < NB; ++bz)
+            for (int dd = 0; dd < 27; ++dd) {
+                const int ox = dd % 3 - 1, oy = (dd / 3) % 3 - 1, oz = dd / 9 - 1;
+                m[(size_t)bid(bx, by, bz) * 32 + dd] = bid((bx + ox + NB) % NB, (by + oy + NB) % NB, (bz + oz + NB) % NB);
+            }
+        CK(hipMalloc(&d_meta, m.size() * 4));
+        CK(hipMemcpy(d_meta, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+    }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 
@@ -358,6 +380,19 @@ int main(int argc, char **argv)
         all.push_back(sched_xmarch(2, 32, true));
         all.push_back(sched_xmarch(2, 16, true));
         all.push_back(sched_xmarch(1, 32, false));
+    }
+    if (strchr(sel, '3')) {
+        auto with = [&](const char *nm, int variant, int hm) { Sched c = sched_current(); c.name = nm; c.variant = variant; c.halo_mask = hm; all.push_back(c); };
+        with("cur, all halos", 0, ~0);
+        with("cur, only T/B velocity planes", 0, F_C | F_B | F_T);
+        with("cur, only y rows (S/N)", 0, F_C | F_S | F_N);
+        with("cur, only outer x columns (W/E)", 0, F_C | F_W | F_E);
+        with("cur, y rows + x columns", 0, F_C | F_S | F_N | F_W | F_E);
+        with("cur, all halos, dependent neighbour-id load", 1, ~0);
+        with("cur, all halos, 5 waves/SIMD", 2, ~0);
+        with("cur, all halos, dependent load + 5 waves/SIMD", 3, ~0);
+        with("cur, all halos, 3 waves/SIMD", 4, ~0);
+        with("cur, all halos (again)", 0, ~0);
     }
     if (strchr(sel, '2')) {
         all.push_back(sched_current());
@@ -395,7 +430,7 @@ int main(int argc, char **argv)
         float res[2];
         for (int pass = 0; pass < 2; ++pass) {
             // pass 0: no halo fetches, velocity: centre plane only (every item) = the 244 B/cell floor of this schedule
-            const int mask = pass == 0 ? (ID_MASK | F_C) : ~0;
+            const int mask = pass == 0 ? (ID_MASK | F_C) : (s.halo_mask | ID_MASK);
             std::vector<int> it2;
             if (pass == 0) {   // the floor needs the centre plane on every item
                 it2 = s.items;
@@ -406,9 +441,15 @@ int main(int argc, char **argv)
             for (int r = 0; r < reps + 2; ++r) {
                 CK(hipEventRecord(e0));
                 switch (s.nw) {
-                case 4: hipLaunchKernelGGL(k_march<4>, dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask); break;
-                case 8: hipLaunchKernelGGL(k_march<8>, dim3(grid), dim3(512), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask); break;
-                case 16: hipLaunchKernelGGL(k_march<16>, dim3(grid), dim3(1024), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask); break;
+                case 4:
+                    if (s.variant == 0) hipLaunchKernelGGL(k_march<4>, dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
+                    else if (s.variant == 1) hipLaunchKernelGGL((k_march<4, true, 0>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
+                    else if (s.variant == 2) hipLaunchKernelGGL((k_march<4, false, 5>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
+                    else if (s.variant == 3) hipLaunchKernelGGL((k_march<4, true, 5>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
+                    else hipLaunchKernelGGL((k_march<4, false, 3>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
+                    break;
+                case 8: hipLaunchKernelGGL(k_march<8>, dim3(grid), dim3(512), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta); break;
+                case 16: hipLaunchKernelGGL(k_march<16>, dim3(grid), dim3(1024), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta); break;
                 default: printf("bad nw\n"); return 1;
                 }
                 CK(hipEventRecord(e1));
