@@ -97,3 +97,82 @@ def test_wing_on_two_ranks_equals_single_device(gpu, wing, tmp_path):
     d = read_vtu(os.path.join(res, "flow_000040.vtu"))
     assert d["n_cells"] == 512 * len(output.select_export_blocks([g.active_block_coords for g in grids]))
     assert np.isfinite(d["Velocity"]).all() and np.abs(d["Velocity"]).max() > 0 and "Density" not in d      # density: false in this case's config
+
+
+# ---- BASELINE configs[4] on its OWN geometry: CASES/Wing_5_deg/model5deg.stl (63 196 triangles, kept as a data fixture) ----
+# The shipped configuration is 5 levels at 1 100 cells per 14 m; BASELINE names the 3-level variant. Overrides, stated:
+# num_levels 3, surface_resolution 200 (dx_fine = 0.07 m; 2 090 / 1 728 / 5 256 blocks = 4.65 M cells, 13.6 M cell updates per
+# coarse step, 67 096 Bouzidi cells), ramp_steps 40 so that 24 coarse steps already load the wing. Everything else as shipped:
+# symmetric half model (the STL holds both halves: the y < 0 half lies outside the domain), wall model, inlet turbulence 1 %,
+# Bouzidi on the finest level, temporal interpolation. The reference holds no log or result file for this case, so its setup
+# integers below pin this repository's restatement only (parity of the setup: unpinned); the stepping is HIP vs oracle.
+REAL_OVERRIDES = {"basic": {"surface_resolution": 200, "num_levels": 3, "simulation": {"ramp_steps": 40}}}
+
+
+@pytest.fixture(scope="module")
+def wing_real():
+    cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"), REAL_OVERRIDES)
+    cfg.diag_freq = 8
+    return cfg, os.path.join(G, "wing5deg_model.stl")
+
+
+def test_real_wing_setup(wing_real):
+    cfg, stl = wing_real
+    grids, mesh, params, rep = pp.setup_multilevel_domain(cfg, stl)
+    assert mesh.triangles.shape[0] == 63196
+    assert rep.level_blocks == [2090, 1728, 5256] and rep.bouzidi_cells == [67096] and rep.flood_fill_filled == [143, 4619, 56967]
+    assert (params.bx_max, params.by_max, params.bz_max) == (19, 11, 10) and params.mesh_offset[1] == 0.0
+    fin = grids[-1]
+    assert fin.obstacle[:, 0, :, fin.map_y == 1].any(), "the root section cuts the symmetry plane"
+    near = (fin.wall_dist > 0) & (fin.wall_dist < 10)
+    assert near.sum() > 30_000                                  # wall-model cells all around a thin, non-convex body
+    assert float(grids[0].tau) == pytest.approx(0.5000086, abs=1e-7)
+
+
+@pytest.mark.gpu
+def test_real_wing_hip_equals_oracle(gpu, wing_real):
+    """24 coarse steps (326 M cell updates) of the real wing on HIP and on the CPU oracle: every level's rho / u / f and every
+    Cd / Cl / Cs / Cmy row identical; the HIP stepping rate is printed for profiles/."""
+    import copy
+    import time
+    from _steppers import OracleStepper
+    from oracle import oracle
+    oracle.set_num_threads(16)
+    cfg, stl = wing_real
+    steps = 24
+    setup_h = pp.setup_multilevel_domain(cfg, stl)
+    setup_o = copy.deepcopy(setup_h)
+    keep = {}
+
+    def hip_factory(grids):
+        keep["st"] = case.HipStepper(grids)
+        keep["st"].close = lambda: None
+        return keep["st"]
+
+    hip, _, _ = case.run_case(cfg, hip_factory, steps=steps, setup=setup_h)
+    ora, _, _ = case.run_case(cfg, OracleStepper, steps=steps, setup=setup_o)
+    assert [r.step for r in hip] == [8, 16, 24] == [r.step for r in ora]
+    assert max(abs(r.cd) for r in ora) > 1e-3 and max(abs(r.cl) for r in ora) > 1e-3, "the short ramp must have loaded the wing"
+    for a, b in zip(hip, ora):
+        for name in ("cd", "cl", "cs", "cmy", "rho_min", "u_lat"):
+            assert getattr(a, name) == getattr(b, name), (a.step, name, getattr(a, name), getattr(b, name))
+    for i, g in enumerate(setup_o[0]):
+        fn, vn = oracle.newest_buffers(i, steps)
+        for name in ("rho", vn, fn):
+            x, y = keep["st"].dev[i].download(name), getattr(g, name)
+            assert np.isfinite(y).all()
+            assert np.array_equal(x, y), (i + 1, name, int(np.count_nonzero(x != y)))
+    # stepping rate of the device levels (state left as it is: 40 more coarse steps, timed)
+    from open_ludwig_amd import execute_timestep_batch
+    from open_ludwig_amd.preprocess import solver_params
+    sp = solver_params(cfg, setup_h[2])
+    dev = keep["st"].dev
+    execute_timestep_batch(dev, steps + 1, 8, np.float32(cfg.u_lattice), sp)
+    t0 = time.perf_counter()
+    execute_timestep_batch(dev, steps + 9, 40, np.float32(cfg.u_lattice), sp)
+    ms = (time.perf_counter() - t0) / 40 * 1e3
+    work = sum(g.n_blocks * 512 * 2 ** i for i, g in enumerate(setup_h[0]))
+    print(f"\nreal wing, 3 levels, {sum(g.n_blocks for g in setup_h[0]) * 512 / 1e6:.2f} M cells: {ms:.3f} ms per coarse step = "
+          f"{work / ms / 1e3:.0f} M cell updates/s")
+    for d in dev:
+        d.close()
