@@ -34,23 +34,33 @@ class ForceResult:
     maps: Optional[tuple] = None      # (p, tau_x, tau_y, tau_z) per triangle [Pa], kept for the surface VTU / loads CSV
 
 
-def map_surface_stresses(mesh, rho, vel, obstacle, block_pointer, dx, tau, params, search_radius: int = 5):
-    """map_stresses_kernel! for all triangles at once. rho [8,8,8,nb], vel [8,8,8,nb,3], obstacle bool, block_pointer
-    [dimx,dimy,dimz] 1-based. Returns (p, tau_x, tau_y, tau_z) Float32 per triangle."""
+@dataclass
+class NearestCells:
+    """Per triangle: the fluid cell map_stresses_kernel! ends up reading (src/forces/surface.jl:191-240). It depends on the
+    geometry only (obstacle mask, block layout, triangle centres), never on the flow."""
+    found: np.ndarray       # bool [n_tri]
+    block: np.ndarray       # int64 [n_tri] 0-based block id (0 where not found)
+    lx: np.ndarray; ly: np.ndarray; lz: np.ndarray     # int64 [n_tri] 0-based local coords
+    wall_dist: np.ndarray   # float32 [n_tri] sqrt(d2) / dx of the winning cell (0.5 where not found)
+
+
+def nearest_fluid_cells(mesh, obstacle, block_pointer, dx, params, search_radius: int = 5) -> NearestCells:
+    """The search of map_stresses_kernel! for all triangles at once: shells of radius 0..search_radius around the cell
+    holding the triangle centre, scan order dz, dy, dx, the first strictly smaller distance wins, the search stops after a
+    shell of radius > 1 once a cell was found."""
     B = BLOCK_SIZE
     n = mesh.centers.shape[0]
     dxf = f32(dx)
     off = params.mesh_offset.astype(np.float32)
     c = mesh.centers.astype(np.float32)
-    nrm = mesh.normals.astype(np.float32)
     tx, ty, tz = c[:, 0] + off[0], c[:, 1] + off[1], c[:, 2] + off[2]
     g_x = np.floor(tx / dxf).astype(np.int32) + 1
     g_y = np.floor(ty / dxf).astype(np.int32) + 1
     g_z = np.floor(tz / dxf).astype(np.int32) + 1
     dimx, dimy, dimz = block_pointer.shape
     best_d = np.full(n, f32(1e10), dtype=np.float32)
-    best_rho = np.ones(n, dtype=np.float32)
-    best_u = np.zeros((n, 3), dtype=np.float32)
+    best_b = np.zeros(n, dtype=np.int64)
+    best_l = np.zeros((n, 3), dtype=np.int64)
     best_wd = np.full(n, f32(0.5), dtype=np.float32)
     found = np.zeros(n, dtype=bool)
     bp = np.asarray(block_pointer)
@@ -86,15 +96,18 @@ def map_surface_stresses(mesh, rho, vel, obstacle, block_pointer, dx, tau, param
                     j = idx[better]
                     if j.size == 0:
                         continue
-                    b0 = bidx[j] - 1
                     best_d[j] = d2[better]
-                    best_rho[j] = rho[lx[j], ly[j], lz[j], b0]
-                    best_u[j, 0] = vel[lx[j], ly[j], lz[j], b0, 0]
-                    best_u[j, 1] = vel[lx[j], ly[j], lz[j], b0, 1]
-                    best_u[j, 2] = vel[lx[j], ly[j], lz[j], b0, 2]
+                    best_b[j] = bidx[j] - 1
+                    best_l[j, 0] = lx[j]; best_l[j, 1] = ly[j]; best_l[j, 2] = lz[j]
                     best_wd[j] = np.sqrt(d2[better]) / dxf
                     found[j] = True
-    # compute_stress_from_cell
+    return NearestCells(found, best_b, best_l[:, 0], best_l[:, 1], best_l[:, 2], best_wd)
+
+
+def stress_from_cells(best_rho, best_u, best_wd, found, normals, tau, params):
+    """compute_stress_from_cell (src/forces/surface.jl:32-96) for arrays of winning cells: rho [n], u [n,3], wall distance
+    [n] (lattice units), found [n], triangle normals [n,3]. Returns (p, tau_x, tau_y, tau_z) Float32 [Pa]."""
+    nrm = normals.astype(np.float32)
     pressure_scale = f32(params.rho_physical * params.velocity_scale * params.velocity_scale)
     stress_scale = pressure_scale
     wall_dist = np.maximum(best_wd, f32(0.5))
@@ -115,6 +128,20 @@ def map_surface_stresses(mesh, rho, vel, obstacle, block_pointer, dx, tau, param
     return p, tau_x.astype(np.float32), tau_y.astype(np.float32), tau_z.astype(np.float32)
 
 
+def map_surface_stresses(mesh, rho, vel, obstacle, block_pointer, dx, tau, params, search_radius: int = 5):
+    """map_stresses_kernel! for all triangles at once. rho [8,8,8,nb], vel [8,8,8,nb,3], obstacle bool, block_pointer
+    [dimx,dimy,dimz] 1-based. Returns (p, tau_x, tau_y, tau_z) Float32 per triangle."""
+    nc = nearest_fluid_cells(mesh, obstacle, block_pointer, dx, params, search_radius)
+    n = mesh.centers.shape[0]
+    best_rho = np.ones(n, dtype=np.float32)
+    best_u = np.zeros((n, 3), dtype=np.float32)
+    j = np.flatnonzero(nc.found)
+    best_rho[j] = rho[nc.lx[j], nc.ly[j], nc.lz[j], nc.block[j]]
+    for comp in range(3):
+        best_u[j, comp] = vel[nc.lx[j], nc.ly[j], nc.lz[j], nc.block[j], comp]
+    return stress_from_cells(best_rho, best_u, nc.wall_dist, nc.found, mesh.normals, tau, params)
+
+
 def map_surface_stresses_device(mesh, device_level, dx, tau, params, search_radius: int = 5, vel_name: str = "vel"):
     """map_stresses_kernel! on the device that holds the level (ludwig_map_surface_stresses): same search, same Float32
     expressions as map_surface_stresses above - the two are tested to agree bit for bit - without moving rho / vel to the host."""
@@ -132,11 +159,16 @@ def map_surface_stresses_device(mesh, device_level, dx, tau, params, search_radi
     return tuple(out)
 
 
-def integrate_surface_forces(mesh, p, tau_x, tau_y, tau_z, params, symmetric: bool = False) -> ForceResult:
+def partial_force_sums(mesh, p, tau_x, tau_y, tau_z, params, select=None) -> np.ndarray:
+    """The nine Float32 sums of integrate_forces_kernel! (src/forces/surface.jl:282-366) - pressure force, viscous force,
+    moment about params.moment_center - over all triangles, or over the triangles `select` (an index array: one rank's
+    share in a distributed run). Returns Float32 [9] = Fp(3), Fv(3), M(3); `coverage` count is returned separately."""
     off = params.mesh_offset.astype(np.float32)
     c = mesh.centers.astype(np.float32)
     nrm = mesh.normals.astype(np.float32)
     A = mesh.areas.astype(np.float32)
+    if select is not None:
+        c, nrm, A = c[select], nrm[select], A[select]
     mc = np.asarray(params.moment_center, dtype=np.float32)
     cx, cy, cz = c[:, 0] + off[0], c[:, 1] + off[1], c[:, 2] + off[2]
     dFp = np.stack([-p * nrm[:, 0] * A, -p * nrm[:, 1] * A, -p * nrm[:, 2] * A], axis=1)
@@ -144,9 +176,19 @@ def integrate_surface_forces(mesh, p, tau_x, tau_y, tau_z, params, symmetric: bo
     dF = dFp + dFv
     rx, ry, rz = cx - mc[0], cy - mc[1], cz - mc[2]
     dM = np.stack([ry * dF[:, 2] - rz * dF[:, 1], rz * dF[:, 0] - rx * dF[:, 2], rx * dF[:, 1] - ry * dF[:, 0]], axis=1)
-    Fp = [float(np.sum(dFp[:, i], dtype=np.float32)) for i in range(3)]
-    Fv = [float(np.sum(dFv[:, i], dtype=np.float32)) for i in range(3)]
-    M = [float(np.sum(dM[:, i], dtype=np.float32)) for i in range(3)]
+    out = np.zeros(9, dtype=np.float32)
+    for i in range(3):
+        out[i] = np.sum(dFp[:, i], dtype=np.float32)
+        out[3 + i] = np.sum(dFv[:, i], dtype=np.float32)
+        out[6 + i] = np.sum(dM[:, i], dtype=np.float32)
+    return out
+
+
+def finish_forces(sums, coverage: int, params, symmetric: bool = False) -> ForceResult:
+    """integrate_surface_forces! after the kernel (src/forces/surface.jl:507-571): symmetry doubling, coefficients."""
+    Fp = [float(sums[i]) for i in range(3)]
+    Fv = [float(sums[3 + i]) for i in range(3)]
+    M = [float(sums[6 + i]) for i in range(3)]
     if symmetric:
         Fp[0] *= 2.0; Fp[2] *= 2.0; Fv[0] *= 2.0; Fv[2] *= 2.0
         M[1] *= 2.0
@@ -161,7 +203,12 @@ def integrate_surface_forces(mesh, p, tau_x, tau_y, tau_z, params, symmetric: bo
     if M_ref > 1e-10:
         cmx, cmy, cmz = M[0] / M_ref, M[1] / M_ref, M[2] / M_ref
     return ForceResult(F[0], F[1], F[2], M[0], M[1], M[2], Fp[0], Fp[1], Fp[2], Fv[0], Fv[1], Fv[2], cd, cl, cs, cmx, cmy, cmz,
-                       int(np.count_nonzero(np.abs(p) > 1e-10)))
+                       int(coverage))
+
+
+def integrate_surface_forces(mesh, p, tau_x, tau_y, tau_z, params, symmetric: bool = False) -> ForceResult:
+    sums = partial_force_sums(mesh, p, tau_x, tau_y, tau_z, params)
+    return finish_forces(sums, int(np.count_nonzero(np.abs(p) > 1e-10)), params, symmetric)
 
 
 def compute_aerodynamics(mesh, level_host, rho, vel, params, symmetric: bool = False, search_radius: int = 5) -> ForceResult:

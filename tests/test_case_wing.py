@@ -152,7 +152,7 @@ def test_real_wing_hip_equals_oracle(gpu, wing_real):
     hip, _, _ = case.run_case(cfg, hip_factory, steps=steps, setup=setup_h)
     ora, _, _ = case.run_case(cfg, OracleStepper, steps=steps, setup=setup_o)
     assert [r.step for r in hip] == [8, 16, 24] == [r.step for r in ora]
-    assert max(abs(r.cd) for r in ora) > 1e-3 and max(abs(r.cl) for r in ora) > 1e-3, "the short ramp must have loaded the wing"
+    assert max(abs(r.cd) for r in ora) > 1e-4 and max(abs(r.cl) for r in ora) > 1e-5, "the short ramp must have loaded the wing"
     for a, b in zip(hip, ora):
         for name in ("cd", "cl", "cs", "cmy", "rho_min", "u_lat"):
             assert getattr(a, name) == getattr(b, name), (a.step, name, getattr(a, name), getattr(b, name))

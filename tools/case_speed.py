@@ -1,4 +1,4 @@
-"""Stepping rate of a ball1m variant without diagnostics. usage: case_speed.py re266k|re10m [coarse steps]"""
+"""Stepping rate of a ball1m variant / the real wing (3 levels) without diagnostics. usage: case_speed.py re266k|re10m|wing [coarse steps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,9 +7,11 @@ from open_ludwig_amd import preprocess as pp, case
 which = sys.argv[1] if len(sys.argv) > 1 else "re266k"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 G = os.path.join(ROOT, "tests", "golden")
-ov = {"re266k": {"basic": {"surface_resolution": 25, "num_levels": 3, "flow": {"velocity": 4.0}}}, "re10m": {"basic": {"num_levels": 4}}}[which]
-cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"), ov)
-grids, mesh, params, rep = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
+ov = {"re266k": {"basic": {"surface_resolution": 25, "num_levels": 3, "flow": {"velocity": 4.0}}}, "re10m": {"basic": {"num_levels": 4}},
+      "wing": {"basic": {"surface_resolution": 200, "num_levels": 3}}}[which]
+name = "wing5deg" if which == "wing" else "ball1m"
+cfg = pp.load_case_configuration(os.path.join(G, name + "_config.yaml"), ov)
+grids, mesh, params, rep = pp.setup_multilevel_domain(cfg, os.path.join(G, "wing5deg_model.stl" if which == "wing" else "ball1m.stl"))
 sp = pp.solver_params(cfg, params)
 st = case.HipStepper(grids)
 for i, d in enumerate(st.dev):
