@@ -125,10 +125,14 @@ int  ludwig_level_set_stream(LudwigLevel *level, void *hip_stream);
 
 /*
  * Launch order of the stream-collide kernel. One item per WAVE: items[i] = (block0 << 3) | z with block0 0-based
- * and z in 0..7 = the 8x8 z-plane of that block the wave steps; a negative item is an idle wave. Four consecutive
- * items form one 256-thread workgroup, and workgroup g (items 4g..4g+3) is expected on XCD g % 8. Every
+ * and z in 0..7 = the 8x8 z-plane of that block the wave steps; a negative item is an idle wave. Every
  * (block, plane) of the part must appear exactly once. Purely a performance knob (L2 / Infinity-Cache
- * locality); results do not depend on it. Default: "plane-per-XCD", see DESIGN.md.
+ * locality); results do not depend on it. Default: x-runs, plane-per-XCD, see DESIGN.md.
+ * What the library makes of the list: XRUN (4; 8 with LUDWIG_XRUN=8) consecutive items form one workgroup, and workgroup
+ * g is expected on XCD g % 8. A group of XRUN items whose blocks are all of one kind (all 26 neighbours present, or all
+ * with a missing neighbour) keeps its composition and its slot; items of mixed or incomplete groups are re-packed behind
+ * them. Neighbouring items of a group that hold x-adjacent blocks at the same plane exchange their face column through
+ * LDS. Levels below 8 192 owned blocks step both kinds in one launch (LUDWIG_MERGE_CLASSES overrides).
  */
 int  ludwig_level_set_order(LudwigLevel *level, int part, const int32_t *items, int64_t n_items);
 
@@ -195,6 +199,11 @@ typedef struct LudwigSurfaceParams {
 int  ludwig_map_surface_stresses(const LudwigLevel *level, int vel_field, int32_t n_triangles, const float *centers,
                                  const float *normals, const LudwigSurfaceParams *sp,
                                  float *pressure, float *shear_x, float *shear_y, float *shear_z);
+
+/* compute_flow_stats (src/diagnostics.jl:56-94, CUDA branch), the rho_min column of the run log: minimum of rho over the
+ * non-obstacle cells of the blocks this device owns, reduced on the device (+inf for a level without owned blocks). A
+ * multi-GPU caller takes the minimum over ranks (one all-reduce MIN). */
+int  ludwig_level_rho_min(const LudwigLevel *level, float *rho_min);
 
 /* ---- halo exchange helpers (no reference counterpart: the reference is single-device) ---- */
 /* dst[i] = field[index[i]] / field[index[i]] = src[i]; index, dst, src are DEVICE pointers, index holds element

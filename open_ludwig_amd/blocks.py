@@ -304,6 +304,12 @@ class DeviceLevel:
         _lib.check(self._lib.ludwig_level_field_ptr(self.handle, _lib.FIELD_NAMES[name], C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def rho_min(self) -> float:
+        """rho_min of compute_flow_stats (src/diagnostics.jl:56-94) over the owned, non-obstacle cells, reduced on the device"""
+        v = C.c_float()
+        _lib.check(self._lib.ludwig_level_rho_min(self.handle, C.byref(v)))
+        return float(v.value)
+
     def init_equilibrium(self) -> None:
         """init_eq! (src/main.jl:109-134)"""
         _lib.check(self._lib.ludwig_init_equilibrium(self.handle))

@@ -1040,6 +1040,19 @@ __global__ __launch_bounds__(128) void k_map_stresses(const SurfaceParams s)
     s.p[i] = p; s.tx[i] = sx; s.ty[i] = sy; s.tz[i] = sz;
 }
 
+// ---- compute_flow_stats, reference src/diagnostics.jl:56-94 (CUDA branch): minimum of rho over non-obstacle cells ----
+// rho > 0 always (clamped at 0.01, obstacle cells hold 1), so the IEEE bit pattern orders like the value and an integer
+// atomicMin does the job; a minimum does not depend on the order of its operands: identical to any host reduction.
+__global__ __launch_bounds__(256) void k_rho_min(const float *__restrict__ rho, const uint8_t *__restrict__ obstacle, int64_t n, int *__restrict__ out)
+{
+    float m = __int_as_float(0x7f800000);   // +inf
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        if (!obstacle[i]) m = fminf(m, rho[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(out, __float_as_int(m));
+}
+
 // ---- halo pack / unpack ----
 __global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst)
 {

@@ -107,6 +107,7 @@ struct LudwigLevel {
         int64_t t_sub = -1;
         SCParams p;
     } rho_replay[N_PARTS];
+    int64_t step_count = 0, last_step_t = -1, last_replay_step = -10;   // a level asked for rho after two steps in a row turns eager
     uint64_t version = 0;               // bumped by everything that writes this level's fields
     const LudwigLevel *iface_parent = nullptr;
     std::vector<int32_t> h_block_pointer;   // [gdx,gdy,gdz] 1-based, 0 = absent (src/blocks.jl:111-114)
@@ -581,6 +582,7 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     }
     {
         static const bool eager_env = getenv("LUDWIG_EAGER_RHO") != nullptr || getenv("LUDWIG_NO_XRUN") != nullptr;
+        if (t_sub != L->last_step_t) { ++L->step_count; L->last_step_t = t_sub; }
         const bool store = L->rho_eager || eager_env;
         // whole-level launches and part launches do not mix in one bookkeeping: settle the other kind first
         if (part != LUDWIG_PART_ALL && L->rho_replay[LUDWIG_PART_ALL].stale) {
@@ -679,6 +681,10 @@ int ensure_rho(LudwigLevel *L)
     for (int a = 0; a < N_PARTS; ++a) any = any || L->rho_replay[a].stale;
     if (!any) return LUDWIG_OK;
     LW_HIP(hipSetDevice(L->device));
+    // somebody reads rho after every step (e.g. a peer rank's finer blocks interpolate from this rank's cells: the halo pack
+    // of rho): replaying costs a second pass over f each time, storing costs 4 B per cell - switch
+    if (L->last_replay_step == L->step_count - 1) L->rho_eager = true;
+    L->last_replay_step = L->step_count;
     for (int part = 0; part < N_PARTS; ++part) {
         LudwigLevel::RhoReplay &rr = L->rho_replay[part];
         if (!rr.stale) continue;
@@ -1171,6 +1177,34 @@ int ludwig_map_surface_stresses(const LudwigLevel *L, int vel_field, int32_t n_t
     return LUDWIG_OK;
 }
 
+int ludwig_level_rho_min(const LudwigLevel *L, float *rho_min)
+{
+    if (!L || !rho_min) return fail(LUDWIG_ERR_INVALID, "null argument");
+    *rho_min = __builtin_inff();
+    if (L->n_owned == 0) return LUDWIG_OK;
+    LW_HIP(hipSetDevice(L->device));
+    {
+        const int r = ensure_rho(const_cast<LudwigLevel *>(L));
+        if (r) return r;
+    }
+    int *d = nullptr;
+    LW_HIP(hipMalloc((void **)&d, sizeof(int)));
+    const int inf_bits = 0x7f800000;
+    hipError_t e = hipMemcpyAsync(d, &inf_bits, sizeof(int), hipMemcpyHostToDevice, L->stream);
+    const int64_t n = (int64_t)L->n_owned * CELLS;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_rho_min, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, L->stream, L->rho, L->obstacle, n, d);
+        e = hipGetLastError();
+    }
+    int bits = inf_bits;
+    if (e == hipSuccess) e = hipMemcpyAsync(&bits, d, sizeof(int), hipMemcpyDeviceToHost, L->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(LUDWIG_ERR_HIP, "rho_min: %s", hipGetErrorString(e));
+    memcpy(rho_min, &bits, sizeof(float));
+    return LUDWIG_OK;
+}
+
 int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, int64_t n, float *dst_dev, void *hip_stream)
 {
     if (!L || (n > 0 && (!index_dev || !dst_dev))) return fail(LUDWIG_ERR_INVALID, "null argument");
@@ -1179,8 +1213,12 @@ int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, 
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be packed", field);
     LW_HIP(hipSetDevice(L->device));
     if (field == LUDWIG_RHO) {
+        bool stale = false;
+        for (int a = 0; a < N_PARTS; ++a) stale = stale || L->rho_replay[a].stale;
         const int r = ensure_rho(const_cast<LudwigLevel *>(L));
         if (r) return r;
+        // the replay ran on the level's stream: a pack queued on another stream must not overtake it
+        if (stale && hip_stream && (hipStream_t)hip_stream != L->stream) LW_HIP(hipStreamSynchronize(L->stream));
     }
     hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev);
     LW_HIP(hipGetLastError());

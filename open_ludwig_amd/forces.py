@@ -206,6 +206,24 @@ def finish_forces(sums, coverage: int, params, symmetric: bool = False) -> Force
                        int(coverage))
 
 
+def combine_partial_sums(part: np.ndarray, comm_device=None):
+    """Distributed integrate_forces_kernel!: `part` = this rank's Float32 [10] (nine sums + coverage count). One all-gather
+    of 10 floats per rank over the default torch.distributed group, then every rank adds the rows in rank order in Float32 -
+    deterministic, the same on every rank, independent of the collective's internal order. Returns (sums [9], coverage)."""
+    import torch
+    import torch.distributed as dist
+    mine = torch.as_tensor(np.asarray(part, dtype=np.float32), device=comm_device if comm_device is not None else torch.device("cpu"))
+    rows = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, mine)
+    total = np.zeros(9, dtype=np.float32)
+    cov = 0
+    for a in rows:
+        a = a.cpu().numpy()
+        total = (total + a[:9]).astype(np.float32)
+        cov += int(a[9])
+    return total, cov
+
+
 def integrate_surface_forces(mesh, p, tau_x, tau_y, tau_z, params, symmetric: bool = False) -> ForceResult:
     sums = partial_force_sums(mesh, p, tau_x, tau_y, tau_z, params)
     return finish_forces(sums, int(np.count_nonzero(np.abs(p) > 1e-10)), params, symmetric)

@@ -272,6 +272,9 @@ class HaloExchanger:
         self.plan, self.rank = plan, rank
         self.pack, self.unpack = pack, unpack
         self.stage = stage_through_host
+        self.device = torch.device(device)
+        self.timing = False                # bench.py: bracket every exchange with events on the stream it runs on
+        self._events = []
         self.idx_send, self.idx_recv, self.buf_send, self.buf_recv, self.seg_send, self.seg_recv = {}, {}, {}, {}, {}, {}
         for name in FIELD_GROUPS:
             s_lists = [plan.send[p][name] for p in plan.peers]
@@ -302,13 +305,17 @@ class HaloExchanger:
         import torch.distributed as dist
         torch = self.torch
         names = tuple(fields)
+        on_gpu = self.device.type == "cuda"
+        if self.timing and on_gpu:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         for n in names:
             if self.buf_send[n].numel():
                 self.pack(fields[n], self.idx_send[n], self.buf_send[n])
         if self.stage:
             for n in names:
                 self.host_send[n].copy_(self.buf_send[n], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(self.device).synchronize()
         snd = self.host_send if self.stage else self.buf_send
         rcv = self.host_recv if self.stage else self.buf_recv
         ops = []
@@ -333,6 +340,15 @@ class HaloExchanger:
         for n in names:
             if self.buf_recv[n].numel():
                 self.unpack(fields[n], self.idx_recv[n], self.buf_recv[n])
+        if self.timing and on_gpu:
+            e1.record(torch.cuda.current_stream(self.device))
+            self._events.append((e0, e1))
+
+    def exchange_ms(self) -> List[float]:
+        """elapsed time of every timed exchange (pack -> send/recv -> unpack) on its stream; call after a device synchronize"""
+        out = [a.elapsed_time(b) for a, b in self._events]
+        self._events = []
+        return out
 
 
 def exchange_requests(my_requests: Dict[int, Dict[str, np.ndarray]], world: int, rank: int) -> Dict[int, Dict[str, np.ndarray]]:
@@ -378,7 +394,7 @@ def periodic_box_topology(nb_global: Tuple[int, int, int], grid: Tuple[int, int,
 class DistributedLevelRunner:
     """GPU path: one rank's local level on one MI355X + halo exchange; step(t) = one stream-collide pass everywhere.
 
-    overlap=True: boundary blocks first, then (interior kernel) || (pack, send/recv, unpack on a second HIP stream).
+    overlap=True: see step() - the exchange of step t runs on a second HIP stream under the interior blocks of step t + 1.
     """
 
     def __init__(self, view: LocalView, plan: HaloPlan, params, device: int, overlap: bool = True,
@@ -390,6 +406,7 @@ class DistributedLevelRunner:
         from . import order as order_mod
         self.torch, self._lib, self.C = torch, _lib, C
         self.view, self.params, self.overlap = view, params, overlap
+        torch.cuda.set_device(device)
         self.level = adapt(view.level, device)
         self.dev = torch.device("cuda", device)
         self.s_comp = torch.cuda.current_stream(self.dev)
@@ -422,39 +439,39 @@ class DistributedLevelRunner:
         self._have_exchange = False
 
     def step(self, t: int, u_curr=0.0) -> None:
-        from .physics import stream_collide
+        """One step with the halo exchange hidden behind the NEXT step's interior blocks:
+             compute stream : interior(t) | wait exchange(t-1) | boundary(t) | [f_post halo, Bouzidi correction(t)]
+             comm stream    :  ... exchange(t-1) ...                                            | exchange(t) ...
+        Interior blocks (no ghost neighbour) read and write owned cells only, so they may run while the ghosts of their input
+        are still arriving; the boundary blocks wait for them. Levels with Bouzidi cells follow the same schedule: the
+        correction rewrites f_out after the collision from the post-collision values of neighbour cells, so its small
+        f_post halo (only the links that reach across a cut) is exchanged in between, and the f / u halo goes last."""
+        from .physics import apply_bouzidi_correction, stream_collide
         _lib = self._lib
         torch = self.torch
         out_f, out_v = ("f_temp", "vel_temp") if t % 2 == 0 else ("f", "vel")
-        if self._have_exchange:
-            self.s_comp.wait_event(self.ev_exchanged)       # ghosts of this step's input are in place
-        if self.level.has_post_collision:
-            # Bouzidi level: the correction rewrites f_out at boundary cells AFTER the collision and reads the post-collision
-            # populations of neighbour cells, so: collide everything -> f_post halo -> correction -> f / u halo (no overlap)
-            from .physics import apply_bouzidi_correction
-            stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_ALL)
-            with torch.cuda.stream(self.s_comm):
-                self.ev_boundary.record(self.s_comp)
-                self.s_comm.wait_event(self.ev_boundary)
-                if self.ex.plan.has("f_post"):
-                    self.ex.exchange_post_collision()
-                self.ev_exchanged.record(self.s_comm)
-            self.s_comp.wait_event(self.ev_exchanged)
-            apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
-            with torch.cuda.stream(self.s_comm):
-                self.ev_boundary.record(self.s_comp)
-                self.s_comm.wait_event(self.ev_boundary)
-                self.ex.exchange(out_f, out_v)
-                self.ev_exchanged.record(self.s_comm)
-            self._have_exchange = True
-            return
         if not self.overlap:
             stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_ALL)
+            if self.level.has_post_collision:
+                if self.ex.plan.has("f_post"):
+                    self.ex.exchange_post_collision()
+                apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
             self.ex.exchange(out_f, out_v)
             return
-        stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_BOUNDARY)
-        self.ev_boundary.record(self.s_comp)
         stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_INTERIOR)
+        if self._have_exchange:
+            self.s_comp.wait_event(self.ev_exchanged)       # ghosts of this step's input are in place
+        stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_BOUNDARY)
+        if self.level.has_post_collision:
+            if self.ex.plan.has("f_post"):
+                self.ev_boundary.record(self.s_comp)
+                with torch.cuda.stream(self.s_comm):
+                    self.s_comm.wait_event(self.ev_boundary)
+                    self.ex.exchange_post_collision()
+                    self.ev_exchanged.record(self.s_comm)
+                self.s_comp.wait_event(self.ev_exchanged)
+            apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
+        self.ev_boundary.record(self.s_comp)
         with torch.cuda.stream(self.s_comm):
             self.s_comm.wait_event(self.ev_boundary)
             self.ex.exchange(out_f, out_v)
@@ -625,13 +642,13 @@ def interpolation_needs(child: LocalView, parent: LocalView, domain_cells: Tuple
 class MultiLevelRunner:
     """Distributed recursive_step! (src/solver_control.jl:21-143) for nested levels: same call order and A/B parity as
     the single-device driver, plus after every level step the halo exchange of that level (same-level ghosts AND the
-    parent-data ghosts its children interpolate from). Levels are small here, so the exchange is not overlapped.
+    parent-data ghosts its children interpolate from), overlapped with compute on a second HIP stream (_step_level).
 
     owners: one owner array per level (`level_owners`: every level cut on its own, the default of DistributedStepper), or a
     single level-1 array (whole hierarchies per rank: `balanced_owner` + `ancestor_owner`)."""
 
     def __init__(self, grids: Sequence[BlockLevel], owners, params, rank: int, world: int, device: int,
-                 stage_through_host: bool = False):
+                 stage_through_host: bool = False, overlap: bool = True):
         import ctypes as C
         import torch
         from . import _lib
@@ -656,11 +673,11 @@ class MultiLevelRunner:
             slice_level_fields(v, g)
             views[i] = v
         self.views = views
-        # no local copy at all of a level: None (skipped); only ghost copies (parent data for finer blocks): kept, never stepped
-        self.levels = [adapt(v.level, device) if v.level.n_blocks > 0 else None for v in self.views]
+        torch.cuda.set_device(device)
         self.dev = torch.device("cuda", device)
         lib = _lib.load()
-        self.ex: List[HaloExchanger] = []
+        # plans first: which blocks of a level send anything is part of the level's description (comm_boundary)
+        plans: List[HaloPlan] = []
         for i, (v, g) in enumerate(zip(self.views, grids)):
             needs = compute_needs(v) if v.n_owned > 0 else {"f": np.zeros(0, np.int64), "vel": np.zeros(0, np.int64)}
             needs.setdefault("f_post", np.zeros(0, np.int64))
@@ -672,6 +689,32 @@ class MultiLevelRunner:
             mine = make_requests(v, g.n_blocks, needs)
             to_me = exchange_requests(mine, world, rank) if world > 1 else {}
             plan = build_plan(v, g.n_blocks, mine, to_me)
+            plans.append(plan)
+            # "boundary" part = owned blocks next to a ghost block (they read ghosts) AND owned blocks any peer reads from (same-level
+            # halo, or parent data of a peer's finer blocks - those may lie anywhere): stepped first, so that the exchange can run
+            # under the remaining, interior blocks
+            if v.n_owned > 0:
+                sk = 512 * v.level.n_blocks
+                for pr in plan.peers:
+                    for name in FIELD_GROUPS:
+                        off = plan.send[pr][name]
+                        if len(off):
+                            blk = (np.asarray(off, dtype=np.int64) % sk) // 512
+                            v.level.comm_boundary[blk[blk < v.n_owned]] = 1
+        # no local copy at all of a level: None (skipped); only ghost copies (parent data for finer blocks): kept, never stepped
+        self.levels = [adapt(v.level, device) if v.level.n_blocks > 0 else None for v in self.views]
+        self.overlap = overlap
+        self.s_comp = torch.cuda.current_stream(self.dev)
+        self.s_comm = torch.cuda.Stream(self.dev) if overlap else self.s_comp
+        for L in self.levels:
+            if L is not None:
+                L.set_stream(self.s_comp.cuda_stream)
+        self.ex: List[HaloExchanger] = []
+        self.ev_stepped = [torch.cuda.Event() for _ in grids]
+        self.ev_exchanged = [torch.cuda.Event() for _ in grids]
+        self.ev_post = [torch.cuda.Event() for _ in grids]
+        self.pending = [False] * len(grids)          # an exchange of this level is in flight on the comm stream
+        for i, plan in enumerate(plans):
             handle = self.levels[i].handle if self.levels[i] is not None else None
 
             def pack(name, idx, out, handle=handle):
@@ -684,22 +727,76 @@ class MultiLevelRunner:
 
             self.ex.append(HaloExchanger(plan, rank, self.dev, pack, unpack, stage_through_host))
 
-    def _step_level(self, i: int, t_sub: int, parent, parent_tau, tw, u) -> None:
+    def _join(self, i: int) -> None:
+        """the compute stream waits for level i's exchange in flight (its ghosts are about to be read)"""
+        if self.pending[i]:
+            self.s_comp.wait_event(self.ev_exchanged[i])
+            self.pending[i] = False
+
+    def _step_level(self, i: int, t_sub: int, parent, parent_tau, tw, u, has_children: bool) -> None:
+        """One level step + its halo exchange (same-level ghosts and the parent-data ghosts of peers' finer blocks).
+        Overlap (two HIP streams):
+          * a level WITH children: boundary part (every block a ghost or a peer depends on) first, then the exchange on the comm
+            stream under the interior part; the children start when both are done.
+          * the finest level (nobody below reads its ghosts): interior part first - it reads no ghost - while the exchange of
+            its PREVIOUS sub-step is still arriving, then the boundary part, [f_post halo, Bouzidi correction], and its own
+            exchange is left in flight under whatever comes next (the next sub-step's interior part, or a coarser level's step)."""
         from .physics import apply_bouzidi_correction, stream_collide
-        _lib = self._lib
+        _lib, torch = self._lib, self.torch
         L, ex = self.levels[i], self.ex[i]
         stepping = self.views[i].n_owned > 0                 # else: only ghost copies here, refreshed by the exchange below
         out_f, out_v = ("f_temp", "vel_temp") if t_sub % 2 == 0 else ("f", "vel")
-        if stepping:
-            stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
-        if ex.plan.has("f_post"):
-            ex.exchange_post_collision()
-        if stepping and L.has_post_collision:
-            apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
         fields = {"f": out_f, "vel": out_v}
         if ex.plan.has("rho"):
             fields["rho"] = "rho"
-        ex.exchange_fields(fields)
+        if i > 0:
+            self._join(i - 1)                                # the parent's ghosts (interpolation stencils) must be in place
+        if not self.overlap:
+            if stepping:
+                stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
+            if ex.plan.has("f_post"):
+                ex.exchange_post_collision()
+            if stepping and L.has_post_collision:
+                apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
+            ex.exchange_fields(fields)
+            return
+        bouzidi = stepping and L.has_post_collision
+        if has_children and not bouzidi:
+            self._join(i)
+            if stepping:
+                stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_BOUNDARY)
+            self.ev_stepped[i].record(self.s_comp)
+            if stepping:
+                stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_INTERIOR)
+            with torch.cuda.stream(self.s_comm):
+                self.s_comm.wait_event(self.ev_stepped[i])
+                ex.exchange_fields(fields)
+                self.ev_exchanged[i].record(self.s_comm)
+            self.pending[i] = True
+            self._join(i)                                    # children interpolate from this level's ghosts next
+            return
+        if stepping:
+            stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_INTERIOR)
+        self._join(i)
+        if stepping:
+            stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_BOUNDARY)
+        if ex.plan.has("f_post"):
+            self.ev_stepped[i].record(self.s_comp)
+            with torch.cuda.stream(self.s_comm):
+                self.s_comm.wait_event(self.ev_stepped[i])
+                ex.exchange_post_collision()
+                self.ev_post[i].record(self.s_comm)
+            self.s_comp.wait_event(self.ev_post[i])
+        if bouzidi:
+            apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
+        self.ev_stepped[i].record(self.s_comp)
+        with torch.cuda.stream(self.s_comm):
+            self.s_comm.wait_event(self.ev_stepped[i])
+            ex.exchange_fields(fields)
+            self.ev_exchanged[i].record(self.s_comm)
+        self.pending[i] = True
+        if has_children:
+            self._join(i)
 
     def _rec(self, lvl: int, t_sub: int, parent, parent_tau, tw, u) -> None:
         if lvl > len(self.levels):
@@ -708,8 +805,9 @@ class MultiLevelRunner:
         has_children = lvl < len(self.levels)
         if L is not None:
             if has_children and self.params.use_temporal_interp and L.has_temporal_storage:
+                self._join(lvl - 1)
                 L.copy_to_old(t_sub)
-            self._step_level(lvl - 1, t_sub, parent, parent_tau, tw, u)
+            self._step_level(lvl - 1, t_sub, parent, parent_tau, tw, u, has_children)
         if has_children:
             # the level's tau is a property of the level, known on every rank (also where it has no copy of it)
             tau = np.float32(self.views[lvl - 1].level.tau)

@@ -52,6 +52,41 @@ def main():
             oracle.execute_timestep_batch([lvl], t, 1, np.float32(0.0), params)
             ex.exchange(*(("f_temp", "vel_temp") if t % 2 == 0 else ("f", "vel")))
         res = {n: getattr(lvl, n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
+    elif mode == "cpu_forces":
+        # distributed diagnostics without a GPU: a sphere in a tunnel, a flow-like field made up on the host; every rank owns a
+        # slab of blocks, evaluates the stresses of ITS triangles and the nine partial sums, one all-gather combines them
+        import json
+        from open_ludwig_amd import forces, preprocess as pp
+        G = os.path.join(ROOT, "tests", "golden")
+        cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"),
+                                         {"basic": {"surface_resolution": 25, "num_levels": 2, "flow": {"velocity": 4.0}}})
+        grids, mesh, params, rep = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
+        g = grids[-1]
+        rng = np.random.default_rng(5)
+        gx, gy, gz = cases.global_cell_coords(g)
+        rho = (1.0 + 1e-3 * np.sin(0.11 * gx) * np.cos(0.07 * gz) + 1e-5 * rng.standard_normal(g.rho.shape)).astype(np.float32)
+        vel = np.zeros(g.vel.shape, dtype=np.float32, order="F")
+        vel[..., 0] = 0.03 * np.cos(0.05 * gy); vel[..., 1] = 0.01 * np.sin(0.09 * gx); vel[..., 2] = 0.02 * np.sin(0.04 * gz + 0.3)
+        owner = (np.asarray(g.active_block_coords)[:, 0] * 7 + np.asarray(g.active_block_coords)[:, 2] * 3) % world      # scattered ownership
+        nc = forces.nearest_fluid_cells(mesh, g.obstacle, g.block_pointer, g.dx, params, 5)
+        sel = np.flatnonzero(nc.found & (owner[nc.block] == rank))
+        rho_c = rho[nc.lx[sel], nc.ly[sel], nc.lz[sel], nc.block[sel]]
+        u_c = np.stack([vel[nc.lx[sel], nc.ly[sel], nc.lz[sel], nc.block[sel], c] for c in range(3)], axis=1)
+        p, tx, ty, tz = forces.stress_from_cells(rho_c, u_c, nc.wall_dist[sel], np.ones(sel.size, bool), mesh.normals[sel], g.tau, params)
+        part = np.zeros(10, np.float32)
+        part[:9] = forces.partial_force_sums(mesh, p, tx, ty, tz, params, select=sel)
+        part[9] = np.count_nonzero(np.abs(p) > 1e-10)
+        total, cov = forces.combine_partial_sums(part)
+        fr = forces.finish_forces(total, cov, params, False)
+        rmin = torch.tensor([float(rho[:, :, :, owner == rank][~g.obstacle[:, :, :, owner == rank]].min())], dtype=torch.float32)
+        dist.all_reduce(rmin, op=dist.ReduceOp.MIN)
+        single = forces.compute_aerodynamics(mesh, g, rho, vel, params, False)
+        json.dump({"dist": [fr.Cd, fr.Cl, fr.Cs, fr.Cmy, fr.Fx_pressure, fr.Fx_viscous, fr.coverage, float(rmin.item())],
+                   "single": [single.Cd, single.Cl, single.Cs, single.Cmy, single.Fx_pressure, single.Fx_viscous, single.coverage,
+                              float(rho[~g.obstacle].min())], "n_mine": int(sel.size)}, open(os.path.join(outdir, f"forces{rank}.json"), "w"))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     elif mode == "gpu_tunnel":
         # single-level tunnel with sphere, sponge, Bouzidi cells on both sides of the cut; split along x
         grids, params = cases.tunnel_with_sphere(nbg, levels=1, wall_model=False, temporal=False)

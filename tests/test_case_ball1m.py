@@ -120,7 +120,10 @@ def test_cube1m_hip_equals_oracle(gpu):
 @pytest.mark.gpu
 def test_ball1m_on_two_ranks_equals_single_device(gpu, ball_setup, tmp_path):
     """Scope row N3 end to end: the same case through run_case on 2 ranks (cut through all three levels, wall model on,
-    Bouzidi sphere split between the ranks) gives the Cd / Cl / rho_min rows of the single-device run, digit for digit."""
+    Bouzidi sphere split between the ranks). The fields are stepped bit-identically (tests/test_partition_dist.py); the
+    diagnostics cross ranks as scalars only - rho_min by all-reduce MIN (exact), the nine force sums as per-rank partial sums
+    added in rank order, so Cd / Cl equal the single-device rows up to the Float32 rounding of another summation
+    order: 1e-6 of the largest coefficient is asserted."""
     import copy
     import json
     import test_partition_dist as tpd
@@ -132,9 +135,11 @@ def test_ball1m_on_two_ranks_equals_single_device(gpu, ball_setup, tmp_path):
     tpd._launch("gpu_case", tmp_path, (0, 0, 0), steps, world=2)
     rows = json.load(open(os.path.join(tmp_path, "rows.json")))["rows"]
     assert len(rows) == len(single) == 3
+    scale = max(abs(r.cd) for r in single)
     for got, want in zip(rows, single):
         assert got[0] == want.step
-        assert got[1:5] == [want.u_lat, want.rho_min, want.cd, want.cl], (got, want)
+        assert got[1:3] == [want.u_lat, want.rho_min], (got, want)
+        assert abs(got[3] - want.cd) <= 1e-6 * scale and abs(got[4] - want.cl) <= 1e-6 * scale, (got, want)
     stats = [json.load(open(os.path.join(tmp_path, f"stats{r}.json"))) for r in range(2)]
     for lvl in range(3):
         assert sum(s[lvl][0] for s in stats) == setup[0][lvl].n_blocks

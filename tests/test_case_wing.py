@@ -85,8 +85,11 @@ def test_wing_on_two_ranks_equals_single_device(gpu, wing, tmp_path):
     tpd._launch("gpu_case", tmp_path, (1, 0, 0), steps, world=2)
     rows = json.load(open(os.path.join(tmp_path, "rows.json")))["rows"]
     assert len(rows) == len(single) == 3
-    for got, want in zip(rows, single):
-        assert got == [want.step, want.u_lat, want.rho_min, want.cd, want.cl, want.cs, want.cmy], (got, want)
+    scale = max(abs(r.cd) for r in single)
+    for got, want in zip(rows, single):          # forces: per-rank partial sums added in rank order (1e-6); the rest exact
+        assert got[:3] == [want.step, want.u_lat, want.rho_min], (got, want)
+        for a, b in zip(got[3:], [want.cd, want.cl, want.cs, want.cmy]):
+            assert abs(a - b) <= 1e-6 * scale, (got, want)
     # result files: written once (rank 0), from fields gathered over both ranks
     from test_output_files import read_vtu
     from open_ludwig_amd import output

@@ -51,6 +51,26 @@ def test_two_ranks_gloo_cpu(tmp_path):
     _check(tmp_path, nbg, steps, 2)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_force_sums_gloo_cpu(tmp_path, world):
+    """SURVEY 8e diagnostics over gloo: per-rank stresses of the rank's own triangles, nine partial Float32 sums per rank, one
+    all-gather, added in rank order; rho_min by all-reduce MIN. Against the single-domain evaluation of the same fields:
+    coefficients within 1e-6 of the largest one (another summation order), coverage and rho_min exact, same on every rank."""
+    import json
+    _launch("cpu_forces", tmp_path, (0, 0, 0), 0, world=world)
+    res = [json.load(open(os.path.join(tmp_path, f"forces{r}.json"))) for r in range(world)]
+    assert all(r["dist"] == res[0]["dist"] for r in res), "every rank must hold the same totals"
+    assert all(r["n_mine"] > 100 for r in res), "every rank was meant to own part of the surface"
+    d, s = res[0]["dist"], res[0]["single"]
+    scale = max(abs(v) for v in s[:4])
+    assert scale > 1e-3
+    for a, b in zip(d[:4], s[:4]):
+        assert abs(a - b) <= 1e-6 * scale, (d, s)
+    for a, b in zip(d[4:6], s[4:6]):
+        assert abs(a - b) <= 2e-6 * max(abs(s[4]), abs(s[5])), (d, s)
+    assert d[6] == s[6] and d[7] == s[7]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("overlap", [1, 0])
 def test_two_ranks_one_gpu_hip_path(tmp_path, gpu, overlap):
