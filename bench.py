@@ -11,6 +11,10 @@ over every cell of a synthetic uniform periodic box, inputs resident in HBM when
 Prints ONE JSON line (rank 0). `roofline` prices the stream-collide kernel against the 8 TB/s HBM peak with the
 algorithmic 216 B per lattice update; `cpu_baseline` is the CPU oracle (a port, NOT the reference's Julia CPU
 path, which cannot run here) timed on a bounded 64^3 sample of the same workload.
+
+`roofline.traffic` comes from rocprofv3 PMC passes, which cannot run inside this process: it is read from
+profiles/traffic.json and reported ONLY if that file was captured with the very sources the loaded library was built from
+(`source_digest`) on the same workload size; otherwise it is null and `traffic_source` says why. Capture: tools/final_profile.sh.
 """
 from __future__ import annotations
 
@@ -125,6 +129,9 @@ def main():
                                                       overlap=not args.no_overlap, order=args.order,
                                                       stage_through_host=rehearsal)
         level = runner.level
+        if rank == 0:
+            print(f"[bench] backend {dist.get_backend()} reports world size {dist.get_world_size()}; rank grid {partition.rank_grid(world)}; "
+                  f"halo {runner.ex.plan.bytes_per_step() / 1e6:.2f} MB per rank per step", file=sys.stderr, flush=True)
 
         def step(t):
             runner.step(t)
@@ -138,6 +145,9 @@ def main():
     for _ in range(args.warmup):
         step(t); t += 1
     barrier()
+    if runner is not None:
+        runner.ex.exchange_ms()          # drop the warm-up exchanges
+        runner.ex.timing = True
     # timed region: EXACTLY --steps steps; per-launch kernel time from events on the launch stream
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
@@ -147,7 +157,9 @@ def main():
         ev[i][1].record(stream)
     barrier()
     wall = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    per_launch = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = float(np.mean(per_launch))
+    kern_med = float(np.median(per_launch))
 
     if dist is not None:
         red_dev = "cpu" if rehearsal else "cuda"
@@ -159,22 +171,53 @@ def main():
     rho = level.download("rho")
     ok = bool(np.isfinite(rho).all() and rho.std() > 0)
 
+    # multi-GPU: what the exchange cost, measured with events on the stream it ran on (diagnosis of the driver's scaling runs)
+    comm = None
+    if runner is not None:
+        ms = runner.ex.exchange_ms()
+        x = torch.tensor([float(np.mean(ms)) if ms else 0.0, float(np.max(ms)) if ms else 0.0], dtype=torch.float64,
+                         device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(x, op=dist.ReduceOp.MAX)
+        comm = {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(), "rank_grid": list(partition.rank_grid(world)),
+                "halo_bytes_per_rank_per_step": runner.ex.plan.bytes_per_step(), "peers_of_rank0": len([p for p in runner.ex.plan.peers if p != rank]),
+                "exchange_ms_mean_max_over_ranks": round(float(x[0].item()), 4), "exchange_ms_worst": round(float(x[1].item()), 4),
+                "overlap": not args.no_overlap,
+                "note": "exchange = pack -> grouped isend/irecv -> unpack on the comm stream, timed with events on that stream; "
+                        "it runs under the interior blocks of the next step"}
+
     if rank == 0:
         total_cells = cells_per_rank * world
         ms_per_step = wall / args.steps * 1e3
         mlups = total_cells * args.steps / wall / 1e6
         achieved = ALGO_BYTES_PER_LUP * cells_per_rank / (kern_ms * 1e-3) / 1e9      # GB/s, one launch on one GPU
-        traffic = None
+        from open_ludwig_amd import build as build_mod
+        digest = build_mod.source_digest()
+        traffic, traffic_source = None, "profiles/traffic.json absent"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("cells_per_launch") == cells_per_rank:
+                if tj.get("cells_per_launch") != cells_per_rank:
+                    traffic_source = f"profiles/traffic.json is for {tj.get('cells_per_launch')} cells per launch, this run has {cells_per_rank}: not reported"
+                elif tj.get("source_digest") != digest:
+                    traffic_source = (f"profiles/traffic.json was captured with sources {tj.get('source_digest')}, the loaded library is {digest}: "
+                                      "stale, not reported")
+                elif args.order or world > 1 or os.environ.get("LUDWIG_XRUN") or os.environ.get("LUDWIG_EAGER_RHO"):
+                    traffic_source = "profiles/traffic.json is for the default single-GPU launch: not reported for this configuration"
+                else:
                     traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                    traffic_source = (f"replayed from profiles/traffic.json (rocprofv3 PMC passes of tools/final_profile.sh, captured {tj.get('captured', '?')} "
+                                      f"with sources {digest}); not measured inside this process")
+            except Exception as e:
+                traffic_source = f"profiles/traffic.json unreadable: {e}"
+        info = level.info()
+        nw = 8 if os.environ.get("LUDWIG_XRUN") == "8" else 4
+        general = info.n_general_blocks > 0
+        kernel = (f"lw::k_stream_collide_xrun<{nw},{'true' if general and info.n_fast_blocks == 0 else 'false'},false,false> (NW, GENERAL, POST, WALL)"
+                  + ("" if not general or info.n_fast_blocks == 0 else " + the GENERAL instantiation for blocks with a missing neighbour")
+                  + (" [LUDWIG_NO_XRUN: k_stream_collide]" if os.environ.get("LUDWIG_NO_XRUN") else ""))
         out = {
-            "metric": "MLUPS (million lattice updates/s) at 256^3 D3Q27; % of HBM roofline",
+            "metric": f"MLUPS (million lattice updates/s) at {args.size}^3 D3Q27; % of HBM roofline",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -187,10 +230,14 @@ def main():
                        "state_finite": ok},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "lw::k_stream_collide_xrun<4,false,false,false> (NW, GENERAL, POST, WALL)", "kernel_ms": round(kern_ms, 4),
+                         "kernel": kernel, "kernel_ms": round(kern_ms, 4), "kernel_ms_median": round(kern_med, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_LUP * cells_per_rank,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)"},
+                         "traffic_unit": "fabric-side bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",
+                         "traffic_source": traffic_source, "source_digest": digest,
+                         "rho_store": "elided (reproduced on demand, DESIGN 3.1)" if not os.environ.get("LUDWIG_EAGER_RHO") else "eager"},
         }
+        if comm is not None:
+            out["comm"] = comm
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_seconds)
         print(json.dumps(out), flush=True)

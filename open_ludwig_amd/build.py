@@ -18,6 +18,16 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-fno-fast-math", "-Wall", "-Wno-unused-function", "-DLW_NT_STORES"]
 
 
+def source_digest() -> str:
+    """sha1 over the sources the library is built from + the flags: identifies WHICH kernels a measurement belongs to"""
+    import hashlib
+    h = hashlib.sha1(" ".join(HIPCC_FLAGS).encode())
+    for d in sorted(DEPENDS):
+        with open(os.path.join(CSRC, d), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc_path() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -8,7 +8,7 @@ python bench.py > $O/bench.json 2> $O/bench.err
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 100 --warmup 10 --cpu-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 tools/profile_step.py 256 12 > $O/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 tools/profile_step.py 256 12 > $O/pmc_write.log 2>&1
-python3 tools/summarize_profile.py $O/trace $O $O/r01_bench256 16777216 > $O/summary.txt
-cp $O/trace/t_kernel_stats.csv $O/r01_bench256_rocprofv3_kernel_stats.csv
+python3 tools/summarize_profile.py $O/trace $O $O/r02_bench256 16777216 > $O/summary.txt
+cp $O/trace/t_kernel_stats.csv $O/r02_bench256_rocprofv3_kernel_stats.csv
 rm -rf $O/trace/t_kernel_trace.csv $O/pmc_fetch/*kernel_trace.csv $O/pmc_write/*kernel_trace.csv
 cat $O/bench.json; cat $O/bench_under_rocprof.json; cat $O/summary.txt

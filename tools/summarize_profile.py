@@ -33,7 +33,12 @@ if __name__ == "__main__":
         for k in ks:
             f.write(f"{k['kernel'][:70]:70s} {k['calls']:6d} {k['avg_ns']:12.0f} {k['min_ns']:12d} {k['max_ns']:12d} {k['pct']:7.2f}\n")
     c = pmc(glob.glob(os.path.join(pmc_root, "pmc_*")), "k_stream_collide")
-    res = {"cells_per_launch": cells, "counters_per_launch": c}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from open_ludwig_amd import build as build_mod
+    import datetime
+    res = {"cells_per_launch": cells, "counters_per_launch": c, "source_digest": build_mod.source_digest(),
+           "captured": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M UTC"),
+           "kernel": "lw::k_stream_collide_xrun<4,false,false,false> at 256^3, library default order, rho store elided"}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B read requests
         # at 64 B -> double it; WRITE_SIZE is exact. Separate --pmc passes (TCC has 4 slots: FETCH 3 + WRITE 2 do not fit).
