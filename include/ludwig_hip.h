@@ -139,7 +139,12 @@ int  ludwig_level_set_order(LudwigLevel *level, int part, const int32_t *items, 
 /* Array(level.field) / copyto!(level.field, host) */
 int  ludwig_level_upload(LudwigLevel *level, int field, const void *host, size_t bytes);
 int  ludwig_level_download(const LudwigLevel *level, int field, void *host, size_t bytes);
-/* raw device pointer of a field (for halo buffers handed to RCCL by the host side) */
+/* Raw device pointer of a field (e.g. to let RCCL receive straight into it). The pointer stays valid for the life of the
+ * level and the caller may write through it whenever the level's stream is idle. Because the library cannot see such writes,
+ * a level that has handed out a pointer to a state field gives up three internal shortcuts from then on (results are the
+ * same, it is only slower): copy_to_old! really copies, the interface values of its children are no longer computed one
+ * sub-step ahead, rho is stored by every step. Geometry fields (obstacle, sponge, wall_dist) must be changed with
+ * ludwig_level_upload, which also refreshes the per-block flags derived from them. */
 int  ludwig_level_field_ptr(const LudwigLevel *level, int field, void **device_ptr, size_t *bytes);
 
 /* init_eq! (src/main.jl:109-134): f = f_temp = (f_old) = w_k, rho_old = 1, vel_old = 0 */

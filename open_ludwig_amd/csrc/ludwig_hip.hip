@@ -62,6 +62,11 @@ struct LudwigLevel {
     // f / vel ARE f[in] / vel[in] until something else writes that buffer. old_alias = that buffer index, or -1 when the
     // saved state lives in f_old / vel_old (materialize_old() copies it there before any such write). rho is copied.
     int old_alias = -1;
+    // ludwig_level_field_ptr handed out a WRITABLE device pointer (f, f_temp, vel, vel_temp, rho, ...): from then on the caller
+    // may write into the level at any time without the library seeing it, so the three shortcuts that rely on seeing every
+    // write are off for this level - saved state is copied (no aliasing), its children's interface values are not computed
+    // ahead, rho is stored by every step.
+    bool external_writer = false;
     int n_bc = 0;
     int2 *bouzidi_links = nullptr;      // (block * 512 + cell, k) of every listed link with q > 0 (the q map is static)
     int n_bouzidi_links = 0;
@@ -108,6 +113,11 @@ struct LudwigLevel {
         SCParams p;
     } rho_replay[N_PARTS];
     int64_t step_count = 0, last_step_t = -1, last_replay_step = -10;   // a level asked for rho after two steps in a row turns eager
+    // ludwig_execute_timestep_batch runs every level on a stream of its own (level_streams below): events that order them
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_stepped = nullptr;    // recorded on this level's stream after each of its steps (collision + Bouzidi)
+    hipEvent_t ev_consumed = nullptr;   // recorded on the CHILD's stream once its interface pass has read this level's buffers
+    bool ev_consumed_set = false;
     uint64_t version = 0;               // bumped by everything that writes this level's fields
     const LudwigLevel *iface_parent = nullptr;
     std::vector<int32_t> h_block_pointer;   // [gdx,gdy,gdz] 1-based, 0 = absent (src/blocks.jl:111-114)
@@ -617,7 +627,7 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
                 p.f_iface = L->f_iface2;          // computed together with the previous sub-step's values
             } else {
                 // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
-                const bool two = (t_sub % 2 == 0) && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
+                const bool two = (t_sub % 2 == 0) && !parent->external_writer && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
                 InterfaceArgs a{};
                 a.corners = L->sources[part]; a.weights = L->source_w[part];
                 a.mac = L->source_mac[part]; a.mac2 = L->source_mac2[part];
@@ -636,6 +646,12 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
                     hipLaunchKernelGGL(k_interface_links<false>, gl, dim3(256), 0, L->stream, p, a);
                 }
                 LW_HIP(hipGetLastError());
+                // level streams (ludwig_execute_timestep_batch): the parent's buffers have been read - the last time for this
+                // pair of sub-steps when the values for the second one were produced alongside
+                if (parent->ev_consumed && L->own_stream && L->stream == L->own_stream) {
+                    LW_HIP(hipEventRecord(parent->ev_consumed, L->stream));
+                    const_cast<LudwigLevel *>(parent)->ev_consumed_set = true;
+                }
             }
         }
     }
@@ -776,6 +792,9 @@ void ludwig_level_destroy(LudwigLevel *L)
         if (L->source_mac2[a]) (void)hipFree(L->source_mac2[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
+    if (L->own_stream) (void)hipStreamDestroy(L->own_stream);
+    if (L->ev_stepped) (void)hipEventDestroy(L->ev_stepped);
+    if (L->ev_consumed) (void)hipEventDestroy(L->ev_consumed);
     if (L->bouzidi_links) (void)hipFree(L->bouzidi_links);
     if (L->f_iface2) (void)hipFree(L->f_iface2);
     delete L;
@@ -1023,6 +1042,11 @@ int ludwig_level_field_ptr(const LudwigLevel *L, int field, void **device_ptr, s
     }
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || d.bytes == 0) return fail(LUDWIG_ERR_STATE, "field %d is not allocated on this level", field);
+    if (field != LUDWIG_OBSTACLE && field != LUDWIG_SPONGE && field != LUDWIG_WALL_DIST) {   // those three feed per-block flags: upload them
+        LudwigLevel *m = const_cast<LudwigLevel *>(L);
+        m->external_writer = true;
+        m->rho_eager = true;
+    }
     *device_ptr = d.ptr;
     if (bytes) *bytes = d.bytes;
     return LUDWIG_OK;
@@ -1077,7 +1101,13 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
     const size_t c = (size_t)L->sk;
     // f and vel: no copy - the step that follows reads f[in] / vel[in] and never writes them (see old_alias)
     ++L->version;
-    L->old_alias = in;
+    if (L->external_writer) {            // somebody holds raw pointers into f / vel: a real copy, as the reference does
+        L->old_alias = -1;
+        LW_HIP(hipMemcpyAsync(L->f_old, L->f[in], c * Q * 4, hipMemcpyDeviceToDevice, L->stream));
+        LW_HIP(hipMemcpyAsync(L->vel_old, L->vel[in], c * 3 * 4, hipMemcpyDeviceToDevice, L->stream));
+    } else {
+        L->old_alias = in;
+    }
     L->rho_eager = true;                             // a level that saves its old state has children reading rho every step
     {
         const int r = ensure_rho(L);
@@ -1087,20 +1117,37 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
     return LUDWIG_OK;
 }
 
+// Level streams. The reference steps its levels strictly one after the other (src/solver_control.jl:21-143), and every launch
+// of a small level leaves most of the 256 CUs idle. The data dependencies are weaker than the call order: coupling is one-way,
+// coarse -> fine, and a child reads its parent's buffers only in its interface pass (k_interface_sources / _links, once per
+// pair of sub-steps). So each level gets a HIP stream of its own and two events:
+//   * a child's sub-step waits for its parent's step (parent->ev_stepped) before it interpolates from it;
+//   * a parent's NEXT step - which overwrites the buffer holding its old state, rho and rho_old - waits until the child's
+//     interface pass has read them (ev_consumed, recorded on the child's stream right after that pass).
+// Launches are still issued in the reference's order; the GPU then runs level 1's step t + 1 under the finer levels' sub-steps
+// of step t, and a middle level's second sub-step under its children's first pair. Same kernels, same inputs: same bits.
+// LUDWIG_BATCH_SERIAL=1 keeps everything on one stream.
+static bool level_streams() { static const bool v = getenv("LUDWIG_BATCH_SERIAL") == nullptr; return v; }
+
 static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-based*/, int64_t t_sub, const LudwigLevel *parent,
-                          float parent_tau, float temporal_weight, float u_vel, const LudwigStepFlags *fl)
+                          float parent_tau, float temporal_weight, float u_vel, const LudwigStepFlags *fl, bool concurrent)
 {
     // recursive_step! / recursive_step_temporal!, reference src/solver_control.jl:21-143
     if (lvl > n_levels) return LUDWIG_OK;
     LudwigLevel *L = levels[lvl - 1];
     const bool has_children = lvl < n_levels;
     int rc;
+    if (concurrent) {
+        if (has_children && L->ev_consumed_set) LW_HIP(hipStreamWaitEvent(L->stream, L->ev_consumed, 0));
+        if (parent) LW_HIP(hipStreamWaitEvent(L->stream, parent->ev_stepped, 0));
+    }
     if (has_children && fl->use_temporal_interp && L->has_temporal)
         if ((rc = ludwig_save_old(L, t_sub))) return rc;
     if ((rc = ludwig_step(L, parent, t_sub, u_vel, parent_tau, temporal_weight, fl))) return rc;
+    if (concurrent && has_children) LW_HIP(hipEventRecord(L->ev_stepped, L->stream));
     if (has_children) {
-        if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub, L, L->tau, 0.0f, u_vel, fl))) return rc;
-        if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub + 1, L, L->tau, 0.5f, u_vel, fl))) return rc;
+        if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub, L, L->tau, 0.0f, u_vel, fl, concurrent))) return rc;
+        if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub + 1, L, L->tau, 0.5f, u_vel, fl, concurrent))) return rc;
     }
     return LUDWIG_OK;
 }
@@ -1114,10 +1161,43 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
         if (levels[i]->device != levels[0]->device || levels[i]->stream != levels[0]->stream)
             return fail(LUDWIG_ERR_INVALID, "all levels must share one device and one stream");
     }
-    for (int32_t o = 0; o < batch_size; ++o) {
-        const int rc = recursive_step(levels, n_levels, 1, t_start + o, nullptr, 0.5f, 0.0f, u_curr, flags);
-        if (rc) return rc;
+    const bool concurrent = n_levels > 1 && level_streams();
+    hipStream_t user_stream = levels[0]->stream;
+    if (concurrent) {
+        LW_HIP(hipSetDevice(levels[0]->device));
+        LW_HIP(hipStreamSynchronize(user_stream));             // everything queued before the batch is done
+        for (int i = 0; i < n_levels; ++i) {
+            LudwigLevel *L = levels[i];
+            if (!L->own_stream) {
+                LW_HIP(hipStreamCreateWithFlags(&L->own_stream, hipStreamNonBlocking));
+                LW_HIP(hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming));
+                LW_HIP(hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming));
+            }
+            L->ev_consumed_set = false;
+            L->stream = L->own_stream;
+            if (i + 1 < n_levels && !L->rho_eager) {            // children interpolate from rho after every step
+                L->rho_eager = true;
+                const int r = ensure_rho(L);
+                if (r) {
+                    for (int j = 0; j <= i; ++j) levels[j]->stream = user_stream;
+                    return r;
+                }
+            }
+        }
     }
+    int rc = LUDWIG_OK;
+    for (int32_t o = 0; o < batch_size && rc == LUDWIG_OK; ++o)
+        rc = recursive_step(levels, n_levels, 1, t_start + o, nullptr, 0.5f, 0.0f, u_curr, flags, concurrent);
+    if (concurrent) {
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n_levels; ++i) {
+            const hipError_t ei = hipStreamSynchronize(levels[i]->own_stream);
+            if (e == hipSuccess) e = ei;
+            levels[i]->stream = user_stream;
+        }
+        if (rc == LUDWIG_OK && e != hipSuccess) return fail(LUDWIG_ERR_HIP, "batch: %s", hipGetErrorString(e));
+    }
+    if (rc) return rc;
     return ludwig_sync(levels[0]);
 }
 

@@ -78,6 +78,30 @@ def plane_per_xcd_rot(coords, px: int = 4, py: int = 1, sweep: str = "zxy", rot:
     return _per_xcd(seqs)
 
 
+def plane_per_xcd_rot_w8(coords, px: int = 4, py: int = 2, sweep: str = "yxz") -> np.ndarray:
+    """For LUDWIG_XRUN=8 (8 waves per workgroup): a workgroup = one plane of a px x py patch of blocks (px * py = 8), rows
+    of x-consecutive blocks one after the other, so x neighbours sit in neighbouring waves (face column through LDS) and the
+    y neighbour's plane is loaded by a wave of the same workgroup (its lines are in the CU's L1 when the face row is read).
+    Plane z of a patch at block-z bz goes to XCD (z + bz) % 8 as in plane_per_xcd_rot."""
+    assert px * py == 8
+    c = np.asarray(coords).astype(np.int64) - 1
+    seqs = [[] for _ in range(N_XCD)]
+    for blocks in _patches(coords, px, py, sweep):
+        r = int(c[blocks[0], 2])
+        for z in range(8):
+            items = [(int(b) << 3) | z for b in blocks]
+            while len(items) % 8:
+                items.append(-1)
+            for i in range(0, len(items), 8):
+                seqs[(z + r) % N_XCD].append(items[i:i + 8])
+    n = max(len(s2) for s2 in seqs)
+    grid = np.full((n, N_XCD, 8), -1, dtype=np.int64)
+    for x, s2 in enumerate(seqs):
+        if len(s2):
+            grid[: len(s2), x, :] = np.asarray(s2, dtype=np.int64)
+    return grid.reshape(-1).astype(np.int32)
+
+
 def plane_round_robin(coords, px: int = 2, py: int = 2, sweep: str = "xyz") -> np.ndarray:
     """same workgroups as plane_per_xcd but without aiming planes at XCDs: patch after patch, all 8 planes in turn,
     for each workgroup of a large patch -> isolates the effect of workgroup grouping from XCD placement"""
@@ -164,6 +188,9 @@ BUILDERS = {
     "prr_4x1_zxy": lambda c: plane_round_robin(c, 4, 1, "zxy"),
     "pxcd_4x1_zxy": lambda c: plane_per_xcd(c, 4, 1, "zxy"),
     "pxcd_4x1_xzy": lambda c: plane_per_xcd(c, 4, 1, "xzy"),
+    "w8_4x2_yxz": lambda c: plane_per_xcd_rot_w8(c, 4, 2, "yxz"),
+    "w8_8x1_yxz": lambda c: plane_per_xcd_rot_w8(c, 8, 1, "yxz"),
+    "w8_2x4_yxz": lambda c: plane_per_xcd_rot_w8(c, 2, 4, "yxz"),
     "cols_xinner": lambda c: columns(c, 1 << 20, 1),
     "cols_t44": lambda c: columns(c, 4, 4),
     "cols_t22": lambda c: columns(c, 2, 2),

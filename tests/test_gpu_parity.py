@@ -333,3 +333,56 @@ def test_lazy_rho_across_part_launches(gpu):
     oracle.execute_timestep_batch(grids, 3, 2, np.float32(0.0), params)
     assert np.array_equal(d.download("rho"), g.rho)
     d.close()
+
+
+def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
+    """ludwig_level_field_ptr hands out a writable device pointer. The library cannot see writes through it, so the level
+    gives up the shortcuts that depend on seeing every write (aliased saved state, interface values computed one sub-step
+    ahead, elided rho). Here the caller overwrites part of the PARENT's newest populations between the child's two sub-steps,
+    through the pointer: the child's second sub-step must interpolate from the modified parent - checked against the same
+    sequence with the modification made by ludwig_level_upload, which the library does see."""
+    import ctypes as C
+    from open_ludwig_amd.physics import perform_timestep_v2
+    hip = None
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        try:
+            hip = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    assert hip is not None, "HIP runtime not loadable through ctypes"
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    u, t = np.float32(0.05), 1                                       # parent step 1 (odd): in = f_temp, out = f
+
+    def first_half(raw_pointer):
+        grids, params = cases.tunnel_with_sphere((5, 3, 3), levels=2)
+        dev = [adapt(g, 0) for g in grids]
+        ptr = dev[0].field_ptr("f")[0] if raw_pointer else None      # handed out BEFORE the steps: no call in between
+        dev[0].copy_to_old(t)
+        perform_timestep_v2(dev[0], None, np.float32(0.5), u, params, t, np.float32(0.0))
+        perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 2 * t, np.float32(0.0))
+        dev[0].synchronize()
+        return grids, params, dev, ptr
+
+    grids, params, dev, ptr = first_half(True)
+    f_new = dev[0].download("f")
+    patch = np.ascontiguousarray(f_new[..., 5].reshape(-1, order="F") * np.float32(1.01))
+    assert hip.hipMemcpy(C.c_void_p(ptr + 5 * grids[0].rho.size * 4), patch.ctypes.data, patch.nbytes, 1) == 0   # host -> device
+    perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 2 * t + 1, np.float32(0.5))
+    got, got_old = dev[1].download("f"), dev[0].download("f_old")
+
+    _, _, devb, _ = first_half(False)
+    fb = devb[0].download("f")
+    assert np.array_equal(fb, f_new)
+    fb[..., 5] = patch.reshape(fb[..., 5].shape, order="F")
+    devb[0].upload("f", fb)
+    perform_timestep_v2(devb[1], devb[0], devb[0].tau, u, params, 2 * t + 1, np.float32(0.5))
+    assert np.array_equal(got, devb[1].download("f"))
+    assert np.array_equal(got_old, devb[0].download("f_old"))      # the saved state is a real copy, untouched by the write
+
+    _, _, devc, _ = first_half(False)                                # and the write did matter
+    perform_timestep_v2(devc[1], devc[0], devc[0].tau, u, params, 2 * t + 1, np.float32(0.5))
+    assert not np.array_equal(devc[1].download("f"), got)
+    for d in dev + devb + devc:
+        d.close()
