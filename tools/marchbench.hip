@@ -394,6 +394,12 @@ int main(int argc, char **argv)
         with("cur, all halos, 3 waves/SIMD", 4, ~0);
         with("cur, all halos (again)", 0, ~0);
     }
+    if (strchr(sel, '4')) {        // the round-end floor lines (tools/final_profile.sh)
+        all.push_back(sched_current());
+        all.push_back(sched_natural(1));
+        all.push_back(sched_block8());
+        all.push_back(sched_current());
+    }
     if (strchr(sel, '2')) {
         all.push_back(sched_current());
         all.push_back(sched_natural(1));
