@@ -102,6 +102,30 @@ def plane_per_xcd_rot_w8(coords, px: int = 4, py: int = 2, sweep: str = "yxz") -
     return grid.reshape(-1).astype(np.int32)
 
 
+def brick(coords, px: int, py: int, pz: int, rotate: bool = True) -> np.ndarray:
+    """Workgroup = px x-adjacent blocks x py y-adjacent blocks x pz consecutive planes (px * py * pz = LUDWIG_XRUN waves), waves
+    ordered x fastest (same-plane x neighbours in neighbouring waves -> LDS column exchange); blocks visited in MEMORY order (bz
+    fastest, then by, then bx) so that every population stream is read and written sequentially; the 8 / pz plane groups of a
+    brick are consecutive workgroups, rotated with bz. Full boxes whose extents divide by px, py only (bench / tools)."""
+    c = np.asarray(coords).astype(np.int64) - 1
+    nb = c.max(axis=0) + 1
+    lut = np.full(tuple(nb), -1, dtype=np.int64)
+    lut[c[:, 0], c[:, 1], c[:, 2]] = np.arange(len(c))
+    assert (lut >= 0).all() and nb[0] % px == 0 and nb[1] % py == 0
+    ng = 8 // pz
+    out = []
+    for bx0 in range(0, nb[0], px):
+        for by0 in range(0, nb[1], py):
+            for bz in range(nb[2]):
+                for gi in range(ng):
+                    g = (gi + bz) % ng if rotate else gi
+                    for z in range(g * pz, g * pz + pz):
+                        for wy in range(py):
+                            for wx in range(px):
+                                out.append((int(lut[bx0 + wx, by0 + wy, bz]) << 3) | z)
+    return np.asarray(out, dtype=np.int32)
+
+
 def plane_round_robin(coords, px: int = 2, py: int = 2, sweep: str = "xyz") -> np.ndarray:
     """same workgroups as plane_per_xcd but without aiming planes at XCDs: patch after patch, all 8 planes in turn,
     for each workgroup of a large patch -> isolates the effect of workgroup grouping from XCD placement"""
@@ -188,6 +212,15 @@ BUILDERS = {
     "prr_4x1_zxy": lambda c: plane_round_robin(c, 4, 1, "zxy"),
     "pxcd_4x1_zxy": lambda c: plane_per_xcd(c, 4, 1, "zxy"),
     "pxcd_4x1_xzy": lambda c: plane_per_xcd(c, 4, 1, "xzy"),
+    "brick_2x1x2": lambda c: brick(c, 2, 1, 2),
+    "brick_4x1x1": lambda c: brick(c, 4, 1, 1),
+    "brick_2x1x4": lambda c: brick(c, 2, 1, 4),
+    "brick_4x1x2": lambda c: brick(c, 4, 1, 2),
+    "brick_2x2x2": lambda c: brick(c, 2, 2, 2),
+    "brick_2x1x8": lambda c: brick(c, 2, 1, 8, False),
+    "brick_4x1x4": lambda c: brick(c, 4, 1, 4),
+    "brick_2x2x4": lambda c: brick(c, 2, 2, 4),
+    "brick_4x2x2": lambda c: brick(c, 4, 2, 2),
     "w8_4x2_yxz": lambda c: plane_per_xcd_rot_w8(c, 4, 2, "yxz"),
     "w8_8x1_yxz": lambda c: plane_per_xcd_rot_w8(c, 8, 1, "yxz"),
     "w8_2x4_yxz": lambda c: plane_per_xcd_rot_w8(c, 2, 4, "yxz"),

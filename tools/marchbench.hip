@@ -318,6 +318,35 @@ static Sched sched_zmarch_staggered(int PX, int PY)
     return s;
 }
 
+
+// brick: workgroup = PX x-adjacent blocks x PY y-adjacent blocks x PZ consecutive planes (PX * PY * PZ waves), waves ordered x fastest
+// (same-plane x neighbours in neighbouring waves: what the product kernel's LDS column exchange needs). Blocks are visited in
+// MEMORY order (bz fastest, then by, then bx); the 8 / PZ plane groups of a brick are consecutive workgroups, their order rotated
+// with bz so that an XCD does not always see the same plane indices. Halo flags as the PRODUCT kernel would fetch them today:
+// x columns only on the outer x faces of the brick, y rows and z+-1 velocity planes always (L1 / L2 hits inside the brick).
+static Sched sched_brick(int PX, int PY, int PZ, bool rotate)
+{
+    char nm[160];
+    snprintf(nm, sizeof nm, "brick %dx%dx%d (x, y blocks, planes), memory order%s", PX, PY, PZ, rotate ? ", plane groups rotated with bz" : "");
+    Sched s{nm, PX * PY * PZ, 1, {}};
+    const int NB = NBg, ng = 8 / PZ;
+    for (int bx0 = 0; bx0 < NB; bx0 += PX)
+        for (int by0 = 0; by0 < NB; by0 += PY)
+            for (int bz = 0; bz < NB; ++bz)
+                for (int gi = 0; gi < ng; ++gi) {
+                    const int g = rotate ? (gi + bz) % ng : gi;
+                    for (int pz = 0; pz < PZ; ++pz)
+                        for (int wy = 0; wy < PY; ++wy)
+                            for (int wx = 0; wx < PX; ++wx) {
+                                int fl = F_C | F_B | F_T | F_S | F_N;
+                                if (wx == 0) fl |= F_W;
+                                if (wx == PX - 1) fl |= F_E;
+                                s.items.push_back(((bid(bx0 + wx, by0 + wy, bz) << 3) | (g * PZ + pz)) | fl);
+                            }
+                }
+    return s;
+}
+
 // natural: block order, 4 consecutive planes per workgroup, nothing shared
 static Sched sched_natural(int niter)
 {
@@ -393,6 +422,36 @@ int main(int argc, char **argv)
         with("cur, all halos, dependent load + 5 waves/SIMD", 3, ~0);
         with("cur, all halos, 3 waves/SIMD", 4, ~0);
         with("cur, all halos (again)", 0, ~0);
+    }
+    if (strchr(sel, '6')) {        // bricks in memory order: orders the product kernel can run as it is (LUDWIG_XRUN = waves per workgroup)
+        all.push_back(sched_current());
+        all.push_back(sched_pair16(2));
+        all.push_back(sched_brick(2, 1, 2, true));
+        all.push_back(sched_brick(2, 1, 2, false));
+        all.push_back(sched_brick(4, 1, 1, true));
+        all.push_back(sched_brick(2, 1, 4, true));
+        all.push_back(sched_brick(4, 1, 2, true));
+        all.push_back(sched_brick(2, 2, 2, true));
+        all.push_back(sched_brick(2, 1, 8, false));
+        all.push_back(sched_brick(4, 1, 4, true));
+        all.push_back(sched_brick(2, 2, 4, true));
+        all.push_back(sched_brick(4, 2, 2, true));
+        all.push_back(sched_current());
+    }
+    if (strchr(sel, '5')) {        // DRAM-order study: which sweeps of x-run workgroups keep the natural order's floor?
+        all.push_back(sched_current());
+        all.push_back(sched_natural(1));
+        all.push_back(sched_block8());
+        all.push_back(sched_pair16(2));
+        all.push_back(sched_xrun("zyx", 0));
+        all.push_back(sched_xrun("zxy", 0));
+        all.push_back(sched_xrun("yzx", 0));
+        all.push_back(sched_xrun("xyz", 0));
+        all.push_back(sched_xrun("zyYx", 2));
+        all.push_back(sched_xrun("zyYx", 4));
+        all.push_back(sched_xrun("zyYx", 8));
+        all.push_back(sched_xrun("yzYx", 4));
+        all.push_back(sched_current());
     }
     if (strchr(sel, '4')) {        // the round-end floor lines (tools/final_profile.sh)
         all.push_back(sched_current());

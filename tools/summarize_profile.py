@@ -20,7 +20,8 @@ def pmc(dirs, kernel_substr):
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                if kernel_substr in r["Kernel_Name"]:
+                # the RHO_ONLY replay launch (last template argument true) is a different kernel: keep it out of the averages
+                if kernel_substr in r["Kernel_Name"] and ", true>(lw::SCParams)" not in r["Kernel_Name"]:
                     vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in vals.items()}
 
