@@ -38,9 +38,9 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 0 = all-neighbours kernel, 1 = general kernel, 2 = x-run kernel
-constexpr int XRUN_MAX = 16;
-static int xrun_len() { static int v = [] { const char *e = getenv("LUDWIG_XRUN"); int n = e ? atoi(e) : 4; return n == 8 || n == 16 ? n : 4; }(); return v; }
-#define XRUN (xrun_len())               // waves per x-run workgroup: 4 (default), 8 or 16 (LUDWIG_XRUN)
+constexpr int XRUN_MAX = 8;
+static int xrun_len() { static int v = [] { const char *e = getenv("LUDWIG_XRUN"); int n = e ? atoi(e) : 4; return n == 8 ? 8 : 4; }(); return v; }
+#define XRUN (xrun_len())               // waves per x-run workgroup: 4 (default) or 8 (LUDWIG_XRUN=8; 16 was tried: 25 % slower)
 
 }  // namespace
 
@@ -661,8 +661,7 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
         const hipStream_t cs = L->stream;
 #define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, cs, p)
-#define LW_LAUNCH_X(G, P, W) do { if (XRUN == 16) hipLaunchKernelGGL((k_stream_collide_xrun<16, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 16)), dim3(1024), 0, cs, p); \
-            else if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, cs, p); \
+#define LW_LAUNCH_X(G, P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, cs, p); \
             else hipLaunchKernelGGL((k_stream_collide_xrun<4, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, cs, p); } while (0)
         if (c == 0) {
             if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
@@ -714,11 +713,8 @@ int ensure_rho(LudwigLevel *L)
             if (L->n_items[part][c] == 0) continue;
             p.items = L->items[part][c];
             const bool general = c == 1;
-            const dim3 g4((unsigned)(L->n_items[part][c] / 4)), g8((unsigned)(L->n_items[part][c] / 8)), g16((unsigned)(L->n_items[part][c] / 16));
-            if (XRUN == 16) {
-                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<16, true, false, false, true>), g16, dim3(1024), 0, L->stream, p);
-                else hipLaunchKernelGGL((k_stream_collide_xrun<16, false, false, false, true>), g16, dim3(1024), 0, L->stream, p);
-            } else if (XRUN == 8) {
+            const dim3 g4((unsigned)(L->n_items[part][c] / 4)), g8((unsigned)(L->n_items[part][c] / 8));
+            if (XRUN == 8) {
                 if (general) hipLaunchKernelGGL((k_stream_collide_xrun<8, true, false, false, true>), g8, dim3(512), 0, L->stream, p);
                 else hipLaunchKernelGGL((k_stream_collide_xrun<8, false, false, false, true>), g8, dim3(512), 0, L->stream, p);
             } else {
