@@ -139,7 +139,14 @@ int  ludwig_level_set_order(LudwigLevel *level, int part, const int32_t *items, 
 /* Array(level.field) / copyto!(level.field, host) */
 int  ludwig_level_upload(LudwigLevel *level, int field, const void *host, size_t bytes);
 int  ludwig_level_download(const LudwigLevel *level, int field, void *host, size_t bytes);
-/* Raw device pointer of a field (e.g. to let RCCL receive straight into it). The pointer stays valid for the life of the
+/* The device arrays hold the blocks in the library's own order (x-consecutive blocks consecutive in memory), not in the
+ * reference's. Every entry point that takes or returns arrays, block ids or element offsets speaks the REFERENCE order and
+ * translates; only raw pointers (below) expose the internal one: element (cell, block b, component k) of a field lives at
+ * cell + 512 * ref_to_internal[b] + 512 * n_blocks * k. ref_to_internal: [n_blocks], filled by this call (identity when the
+ * environment variable LUDWIG_REFERENCE_BLOCK_ORDER is set). */
+int  ludwig_level_block_order(const LudwigLevel *level, int32_t *ref_to_internal);
+
+/* Raw device pointer of a field (e.g. to let RCCL receive straight into it); blocks in the internal order, see above. The pointer stays valid for the life of the
  * level and the caller may write through it whenever the level's stream is idle. Because the library cannot see such writes,
  * a level that has handed out a pointer to a state field gives up three internal shortcuts from then on (results are the
  * same, it is only slower): copy_to_old! really copies, the interface values of its children are no longer computed one

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "ludwig_level_upload", "ludwig_level_download", "ludwig_level_field_ptr",
     "ludwig_init_equilibrium", "ludwig_step", "ludwig_stream_collide", "ludwig_bouzidi_correction",
     "ludwig_save_old", "ludwig_execute_timestep_batch", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
-    "ludwig_map_surface_stresses", "ludwig_level_rho_min",
+    "ludwig_map_surface_stresses", "ludwig_level_rho_min", "ludwig_level_block_order",
 ]
 
 
@@ -114,6 +114,7 @@ def load() -> C.CDLL:
         "ludwig_map_surface_stresses": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(SurfaceParams), vp, vp, vp, vp]),
         "ludwig_level_info": (C.c_int, [vp, C.POINTER(LevelInfo)]),
         "ludwig_level_rho_min": (C.c_int, [vp, C.POINTER(C.c_float)]),
+        "ludwig_level_block_order": (C.c_int, [vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export what the header declares

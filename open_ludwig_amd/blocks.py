@@ -299,6 +299,12 @@ class DeviceLevel:
         _lib.check(self._lib.ludwig_level_download(self.handle, _lib.FIELD_NAMES[name], a.ctypes.data, a.nbytes))
         return a.view(np.bool_) if name == "obstacle" else a
 
+    def block_order(self) -> np.ndarray:
+        """ref_to_internal [n_blocks]: where the library keeps block b of the reference order (only raw pointers show it)"""
+        a = np.zeros(self.n_blocks, dtype=np.int32)
+        _lib.check(self._lib.ludwig_level_block_order(self.handle, a.ctypes.data))
+        return a
+
     def field_ptr(self, name: str) -> Tuple[int, int]:
         p, n = C.c_void_p(), C.c_size_t()
         _lib.check(self._lib.ludwig_level_field_ptr(self.handle, _lib.FIELD_NAMES[name], C.byref(p), C.byref(n)))

@@ -1053,16 +1053,40 @@ __global__ __launch_bounds__(256) void k_rho_min(const float *__restrict__ rho, 
     if ((threadIdx.x & 63) == 0) atomicMin(out, __float_as_int(m));
 }
 
-// ---- halo pack / unpack ----
-__global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst)
+// ---- internal block order (ludwig_hip.hip "block order"): the caller's arrays keep the reference's block order, the device
+// arrays hold the blocks in the library's own order; ref2int[b_reference] = b_internal ----
+// element offset in the reference layout (cell + 512 b + 512 n_blocks k) -> the same element in the device array
+__device__ __forceinline__ int64_t to_internal_offset(int64_t off, const int32_t *__restrict__ ref2int, int64_t sk)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = field[index[i]];
+    if (!ref2int) return off;
+    const int64_t k = off / sk, r = off - k * sk;
+    return k * sk + (int64_t)ref2int[r >> 9] * CELLS + (r & 511);
 }
-__global__ void k_scatter(float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, const float *__restrict__ src)
+template <class T>
+__global__ __launch_bounds__(256) void k_blocks_to_internal(T *__restrict__ dst, const T *__restrict__ src, const int32_t *__restrict__ ref2int, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[(int64_t)ref2int[i >> 9] * CELLS + (i & 511)] = src[i];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_blocks_to_reference(T *__restrict__ dst, const T *__restrict__ src, const int32_t *__restrict__ ref2int, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[(int64_t)ref2int[i >> 9] * CELLS + (i & 511)];
+}
+
+// ---- halo pack / unpack: index holds element offsets in the REFERENCE layout ----
+__global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst,
+                         const int32_t *__restrict__ ref2int, int64_t sk)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) field[index[i]] = src[i];
+    if (i < n) dst[i] = field[to_internal_offset(index[i], ref2int, sk)];
+}
+__global__ void k_scatter(float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, const float *__restrict__ src,
+                          const int32_t *__restrict__ ref2int, int64_t sk)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) field[to_internal_offset(index[i], ref2int, sk)] = src[i];
 }
 
 }  // namespace lw

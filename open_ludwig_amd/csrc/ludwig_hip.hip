@@ -19,6 +19,7 @@ using namespace lw;
 namespace {
 
 thread_local std::string g_err;
+thread_local bool g_creating_permuted = false;   // ludwig_level_create -> level_create_impl: the description is in internal order
 
 int fail(int code, const char *fmt, ...)
 {
@@ -73,6 +74,17 @@ struct LudwigLevel {
     _Float16 *q_map = nullptr;
     int32_t *cell_block = nullptr;
     int8_t *cell_x = nullptr, *cell_y = nullptr, *cell_z = nullptr;
+    // Block order. The caller's arrays keep the reference's block order (sort of (bx,by,bz) tuples, src/domain.jl:171: bz fastest
+    // in memory, x neighbours 2 MB apart at 256^3). The device arrays hold the blocks in the library's own order - owned blocks
+    // first, each group sorted with bx FASTEST - so that the four x-consecutive blocks an x-run workgroup steps are consecutive
+    // in memory and a sweep "x, then y, then z" reads and writes every population stream sequentially while x / y neighbours stay
+    // close in time in one L2 (the block order's DRAM floor AND the x-run order's halo hits). Everything inside the
+    // library uses internal ids; the ABI translates: create (tables, geometry, Bouzidi lists), upload / download (a block-permuting
+    // copy through `scratch`, one population at a time), halo pack / unpack (offsets translated in the kernel), set_order.
+    std::vector<int32_t> ref2int, int2ref;      // empty = the reference order is kept (LUDWIG_REFERENCE_BLOCK_ORDER, or <= 1 block)
+    bool x_fastest_memory = false;              // known while the default launch order is built (before ref2int is attached)
+    int32_t *d_ref2int = nullptr;
+    void *scratch = nullptr;                    // one population in the reference order (sk floats), allocated on first use
     std::vector<int32_t> h_meta;
     std::vector<uint8_t> h_comm_boundary;
     int32_t *items[N_PARTS][N_CLASSES] = {};
@@ -388,9 +400,16 @@ int default_items(LudwigLevel *L, int part)
         }
         i = j + 1;
     }
-    // sweep: y fastest (y-neighbour groups re-read each other's face rows: next workgroup on the same XCD), then x, then z
-    auto by_zxy = [](const Group &a, const Group &c) {
+    // sweep. Internal block order (x fastest in memory): x fastest, then y, then z = memory order, every population stream is
+    // read and written sequentially, and the x / y neighbour groups follow within a few workgroups on the same XCD.
+    // Reference block order kept (LUDWIG_REFERENCE_BLOCK_ORDER): y fastest, then x, then z (round 1's choice for that layout).
+    const bool x_fastest = L->x_fastest_memory;
+    auto by_zxy = [x_fastest](const Group &a, const Group &c) {
         if (a.bz != c.bz) return a.bz < c.bz;
+        if (x_fastest) {
+            if (a.by != c.by) return a.by < c.by;
+            return a.bx0 < c.bx0;
+        }
         if (a.bx0 != c.bx0) return a.bx0 < c.bx0;
         return a.by < c.by;
     };
@@ -756,6 +775,33 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
     return LUDWIG_OK;
 }
 
+// Host <-> device copy of a whole field between the caller's array (reference block order) and the device array (internal
+// order), one population / component at a time through `scratch`. es = element size (1: obstacle, else 4).
+int copy_field_permuted(LudwigLevel *L, void *dev, void *host, size_t bytes, size_t es, bool to_device)
+{
+    const size_t plane = (size_t)L->sk * es;                 // one population in bytes
+    const size_t K = bytes / plane;
+    if (!L->scratch) LW_HIP(hipMalloc(&L->scratch, (size_t)L->sk * 4));
+    const int64_t n = L->sk;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    for (size_t k = 0; k < K; ++k) {
+        char *d = (char *)dev + k * plane, *h = (char *)host + k * plane;
+        if (to_device) {
+            LW_HIP(hipMemcpyAsync(L->scratch, h, plane, hipMemcpyHostToDevice, L->stream));
+            if (es == 1) hipLaunchKernelGGL(k_blocks_to_internal<uint8_t>, grid, block, 0, L->stream, (uint8_t *)d, (const uint8_t *)L->scratch, L->d_ref2int, n);
+            else hipLaunchKernelGGL(k_blocks_to_internal<float>, grid, block, 0, L->stream, (float *)d, (const float *)L->scratch, L->d_ref2int, n);
+        } else {
+            if (es == 1) hipLaunchKernelGGL(k_blocks_to_reference<uint8_t>, grid, block, 0, L->stream, (uint8_t *)L->scratch, (const uint8_t *)d, L->d_ref2int, n);
+            else hipLaunchKernelGGL(k_blocks_to_reference<float>, grid, block, 0, L->stream, (float *)L->scratch, (const float *)d, L->d_ref2int, n);
+            LW_HIP(hipMemcpyAsync(h, L->scratch, plane, hipMemcpyDeviceToHost, L->stream));
+            LW_HIP(hipStreamSynchronize(L->stream));          // pageable destination: the copy must be over before scratch is reused
+        }
+        LW_HIP(hipGetLastError());
+    }
+    LW_HIP(hipStreamSynchronize(L->stream));
+    return LUDWIG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -792,6 +838,8 @@ void ludwig_level_destroy(LudwigLevel *L)
         if (L->source_mac2[a]) (void)hipFree(L->source_mac2[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
+    if (L->d_ref2int) (void)hipFree(L->d_ref2int);
+    if (L->scratch) (void)hipFree(L->scratch);
     if (L->own_stream) (void)hipStreamDestroy(L->own_stream);
     if (L->ev_stepped) (void)hipEventDestroy(L->ev_stepped);
     if (L->ev_consumed) (void)hipEventDestroy(L->ev_consumed);
@@ -800,7 +848,93 @@ void ludwig_level_destroy(LudwigLevel *L)
     delete L;
 }
 
+static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel **out);
+
 int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
+{
+    if (out) *out = nullptr;
+    if (!h || !out) return fail(LUDWIG_ERR_INVALID, "null argument");
+    const int32_t nb = h->n_blocks;
+    if (nb <= 1 || getenv("LUDWIG_REFERENCE_BLOCK_ORDER") || !h->neighbor_table || !h->map_x || !h->map_y || !h->map_z)
+        return level_create_impl(h, device, out);
+    const int n_owned = h->n_owned > 0 ? h->n_owned : (h->n_owned < 0 ? 0 : nb);
+    if (n_owned > nb) return fail(LUDWIG_ERR_INVALID, "n_owned > n_blocks");
+    // internal order: owned blocks first (as given), inside each group sorted by (bz, by, bx) - bx fastest
+    std::vector<int32_t> int2ref((size_t)nb), ref2int((size_t)nb);
+    for (int32_t b = 0; b < nb; ++b) int2ref[b] = b;
+    std::stable_sort(int2ref.begin(), int2ref.end(), [&](int32_t a, int32_t c) {
+        const bool oa = a < n_owned, oc = c < n_owned;
+        if (oa != oc) return oa;
+        if (h->map_z[a] != h->map_z[c]) return h->map_z[a] < h->map_z[c];
+        if (h->map_y[a] != h->map_y[c]) return h->map_y[a] < h->map_y[c];
+        return h->map_x[a] < h->map_x[c];
+    });
+    for (int32_t i = 0; i < nb; ++i) ref2int[int2ref[i]] = i;
+    // the same description with every per-block array permuted and every block id translated (ids are 1-based, 0 = absent)
+    LudwigLevelHost hp = *h;
+    const size_t n = (size_t)nb;
+    std::vector<int32_t> nt(n * 27), mx(n), my(n), mz(n), bp, cellb;
+    std::vector<uint8_t> obs, cbnd;
+    std::vector<float> spo, wal;
+    std::vector<uint16_t> qm;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t r = (size_t)int2ref[i];
+        mx[i] = h->map_x[r]; my[i] = h->map_y[r]; mz[i] = h->map_z[r];
+        for (int d = 0; d < 27; ++d) {
+            const int32_t v = h->neighbor_table[r + n * d];
+            if (v < 0 || v > nb) return fail(LUDWIG_ERR_INVALID, "neighbor_table[%zu,%d] = %d out of range", r + 1, d + 1, v);
+            nt[i + n * d] = v > 0 ? ref2int[v - 1] + 1 : 0;
+        }
+    }
+    hp.neighbor_table = nt.data(); hp.map_x = mx.data(); hp.map_y = my.data(); hp.map_z = mz.data();
+    auto permute_cells = [&](auto &dst, const auto *src, size_t comps) {
+        dst.resize(n * CELLS * comps);
+        for (size_t k = 0; k < comps; ++k)
+            for (size_t i = 0; i < n; ++i)
+                memcpy(&dst[(k * n + i) * CELLS], &src[(k * n + (size_t)int2ref[i]) * CELLS], CELLS * sizeof(dst[0]));
+    };
+    if (h->obstacle) { permute_cells(obs, h->obstacle, 1); hp.obstacle = obs.data(); }
+    if (h->sponge) { permute_cells(spo, h->sponge, 1); hp.sponge = spo.data(); }
+    if (h->wall_dist) { permute_cells(wal, h->wall_dist, 1); hp.wall_dist = wal.data(); }
+    if (h->bouzidi_q_map && h->n_boundary_cells > 0) { permute_cells(qm, h->bouzidi_q_map, Q); hp.bouzidi_q_map = qm.data(); }
+    if (h->bouzidi_cell_block && h->n_boundary_cells > 0) {
+        cellb.resize((size_t)h->n_boundary_cells);
+        for (int32_t i = 0; i < h->n_boundary_cells; ++i) {
+            const int32_t v = h->bouzidi_cell_block[i];
+            if (v < 1 || v > nb) return fail(LUDWIG_ERR_INVALID, "bouzidi cell %d out of range", i + 1);
+            cellb[i] = ref2int[v - 1] + 1;
+        }
+        hp.bouzidi_cell_block = cellb.data();
+    }
+    if (h->comm_boundary) {
+        cbnd.resize(n);
+        for (size_t i = 0; i < n; ++i) cbnd[i] = h->comm_boundary[int2ref[i]];
+        hp.comm_boundary = cbnd.data();
+    }
+    const size_t nptr = (size_t)h->grid_dim_x * h->grid_dim_y * h->grid_dim_z;
+    if (h->block_pointer && nptr > 0) {
+        bp.resize(nptr);
+        for (size_t i = 0; i < nptr; ++i) {
+            const int32_t v = h->block_pointer[i];
+            if (v < 0 || v > nb) return fail(LUDWIG_ERR_INVALID, "block_pointer[%zu] = %d out of range", i, v);
+            bp[i] = v > 0 ? ref2int[v - 1] + 1 : 0;
+        }
+        hp.block_pointer = bp.data();
+    }
+    g_creating_permuted = true;
+    const int rc = level_create_impl(&hp, device, out);
+    g_creating_permuted = false;
+    if (rc) return rc;
+    LudwigLevel *L = *out;
+    L->ref2int.swap(ref2int);
+    L->int2ref.swap(int2ref);
+    hipError_t e = hipMalloc((void **)&L->d_ref2int, n * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(L->d_ref2int, L->ref2int.data(), n * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { ludwig_level_destroy(L); *out = nullptr; return fail(LUDWIG_ERR_HIP, "block order table: %s", hipGetErrorString(e)); }
+    return LUDWIG_OK;
+}
+
+static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel **out)
 {
     if (out) *out = nullptr;
     if (!h || !out) return fail(LUDWIG_ERR_INVALID, "null argument");
@@ -817,6 +951,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     LudwigLevel *L = new (std::nothrow) LudwigLevel();
     if (!L) return fail(LUDWIG_ERR_ALLOC, "host allocation failed");
     L->device = device;
+    L->x_fastest_memory = g_creating_permuted;
     L->level_id = h->level_id;
     L->n_blocks = h->n_blocks;
     L->n_owned = n_owned;
@@ -992,7 +1127,11 @@ int ludwig_level_set_order(LudwigLevel *L, int part, const int32_t *items, int64
         if (seen[(size_t)items[i]]++) return fail(LUDWIG_ERR_INVALID, "work item %lld listed twice", (long long)i);
     }
     if (real != expect) return fail(LUDWIG_ERR_INVALID, "order has %lld work items, part has %lld", (long long)real, (long long)expect);
-    return set_items(L, part, items, n_items);
+    if (L->ref2int.empty()) return set_items(L, part, items, n_items);
+    std::vector<int32_t> tr(items, items + n_items);           // the caller counts blocks in the reference order
+    for (int32_t &it : tr)
+        if (it >= 0) it = (L->ref2int[it >> 3] << 3) | (it & 7);
+    return set_items(L, part, tr.data(), n_items);
 }
 
 int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t bytes)
@@ -1007,10 +1146,23 @@ int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t byte
         const int r = before_external_write(L, field);
         if (r) return r;
     }
-    LW_HIP(hipMemcpyAsync(field_desc(L, field).ptr, host, bytes, hipMemcpyHostToDevice, L->stream));
-    LW_HIP(hipStreamSynchronize(L->stream));
+    const size_t es = field == LUDWIG_OBSTACLE ? 1 : 4;
+    if (!L->ref2int.empty()) {
+        const int r = copy_field_permuted(L, field_desc(L, field).ptr, const_cast<void *>(host), bytes, es, true);
+        if (r) return r;
+    } else {
+        LW_HIP(hipMemcpyAsync(field_desc(L, field).ptr, host, bytes, hipMemcpyHostToDevice, L->stream));
+        LW_HIP(hipStreamSynchronize(L->stream));
+    }
     if (field == LUDWIG_OBSTACLE || field == LUDWIG_SPONGE || field == LUDWIG_WALL_DIST) {
-        scan_flags(L, field, host);
+        if (!L->ref2int.empty()) {                             // the per-block flags are indexed by internal block id
+            std::vector<char> tmp(bytes);
+            for (size_t i = 0; i < (size_t)L->n_blocks; ++i)
+                memcpy(&tmp[i * CELLS * es], (const char *)host + (size_t)L->int2ref[i] * CELLS * es, CELLS * es);
+            scan_flags(L, field, tmp.data());
+        } else {
+            scan_flags(L, field, host);
+        }
         return upload_meta(L);
     }
     return LUDWIG_OK;
@@ -1027,8 +1179,17 @@ int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t by
         const int r = ensure_rho(const_cast<LudwigLevel *>(L));
         if (r) return r;
     }
+    if (!L->ref2int.empty())
+        return copy_field_permuted(const_cast<LudwigLevel *>(L), d.ptr, host, bytes, field == LUDWIG_OBSTACLE ? 1 : 4, false);
     LW_HIP(hipMemcpyAsync(host, d.ptr, bytes, hipMemcpyDeviceToHost, L->stream));
     LW_HIP(hipStreamSynchronize(L->stream));
+    return LUDWIG_OK;
+}
+
+int ludwig_level_block_order(const LudwigLevel *L, int32_t *ref_to_internal)
+{
+    if (!L || (!ref_to_internal && L->n_blocks > 0)) return fail(LUDWIG_ERR_INVALID, "null argument");
+    for (int32_t b = 0; b < L->n_blocks; ++b) ref_to_internal[b] = L->ref2int.empty() ? b : L->ref2int[b];
     return LUDWIG_OK;
 }
 
@@ -1300,7 +1461,7 @@ int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, 
         // the replay ran on the level's stream: a pack queued on another stream must not overtake it
         if (stale && hip_stream && (hipStream_t)hip_stream != L->stream) LW_HIP(hipStreamSynchronize(L->stream));
     }
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev);
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev, (const int32_t *)L->d_ref2int, L->sk);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -1319,7 +1480,7 @@ int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int6
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be unpacked", field);
     LW_HIP(hipSetDevice(L->device));
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev, (const int32_t *)L->d_ref2int, L->sk);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }

@@ -367,7 +367,11 @@ def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
 
     grids, params, dev, ptr = first_half(True)
     f_new = dev[0].download("f")
-    patch = np.ascontiguousarray(f_new[..., 5].reshape(-1, order="F") * np.float32(1.01))
+    order = dev[0].block_order()                                     # raw pointers show the library's own block order
+    assert sorted(order) == list(range(grids[0].n_blocks)) and not np.array_equal(order, np.arange(grids[0].n_blocks))
+    inv = np.argsort(order)                                          # internal position -> reference block
+    patch_ref = f_new[..., 5] * np.float32(1.01)                     # (8,8,8,nb) in the reference order
+    patch = np.ascontiguousarray(patch_ref[:, :, :, inv].reshape(-1, order="F"))
     assert hip.hipMemcpy(C.c_void_p(ptr + 5 * grids[0].rho.size * 4), patch.ctypes.data, patch.nbytes, 1) == 0   # host -> device
     perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 2 * t + 1, np.float32(0.5))
     got, got_old = dev[1].download("f"), dev[0].download("f_old")
@@ -375,7 +379,7 @@ def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
     _, _, devb, _ = first_half(False)
     fb = devb[0].download("f")
     assert np.array_equal(fb, f_new)
-    fb[..., 5] = patch.reshape(fb[..., 5].shape, order="F")
+    fb[..., 5] = patch_ref
     devb[0].upload("f", fb)
     perform_timestep_v2(devb[1], devb[0], devb[0].tau, u, params, 2 * t + 1, np.float32(0.5))
     assert np.array_equal(got, devb[1].download("f"))

@@ -28,7 +28,7 @@ template <int NW, bool DEP = false, int WPE = 0>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(WPE == 0 ? 1 : WPE, WPE == 0 ? 8 : WPE)))
 void k_march(const float *__restrict__ fin, float *__restrict__ fout, const float *__restrict__ vin,
              float *__restrict__ vout, float *__restrict__ rho, const int *__restrict__ items,
-             int niter, size_t sk, int NB, int mask, const int *__restrict__ meta = nullptr)
+             int niter, size_t sk, int NB, int mask, const int *__restrict__ meta = nullptr, int layout = 0)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, x = lane & 7, y = lane >> 3;
@@ -39,7 +39,7 @@ void k_march(const float *__restrict__ fin, float *__restrict__ fout, const floa
         if (raw < 0) continue;
         const int fl = raw & mask;
         const int id = raw & ID_MASK, b = id >> 3, z = id & 7;
-        const int bz = b % NB, by = (b / NB) % NB, bx = b / (NB * NB);
+        const int bz = layout == 0 ? b % NB : b / (NB * NB), by = (b / NB) % NB, bx = layout == 0 ? b / (NB * NB) : b % NB;
         int nbm[27];
         if (DEP) {     // as the product: the 27 neighbour ids come from a per-block row, a scalar load that depends on the item
 #pragma unroll
@@ -47,7 +47,8 @@ void k_march(const float *__restrict__ fin, float *__restrict__ fout, const floa
         }
         auto blk = [&](int ox, int oy, int oz) {
             if (DEP) return (uint32_t)nbm[(ox + 1) + 3 * (oy + 1) + 9 * (oz + 1)];
-            return (uint32_t)((wrap(bx + ox, NB) * NB + wrap(by + oy, NB)) * NB + wrap(bz + oz, NB));
+            return layout == 0 ? (uint32_t)((wrap(bx + ox, NB) * NB + wrap(by + oy, NB)) * NB + wrap(bz + oz, NB))
+                               : (uint32_t)((wrap(bz + oz, NB) * NB + wrap(by + oy, NB)) * NB + wrap(bx + ox, NB));
         };
         float v[Q];
 #pragma unroll
@@ -120,10 +121,12 @@ struct Sched {
     std::vector<int> items;      // [wg][wave][iter]
     int variant = 0;             // 0 plain, 1 dependent neighbour-id load, 2 capped at 5 waves per SIMD, 3 both
     int halo_mask = ~0;          // which of the design's global fetches the "with halos" pass keeps
+    int layout = 0;              // memory order of the blocks the items were built for (g_layout at build time)
 };
 
 static int NBg = 32;
-static int bid(int bx, int by, int bz) { return (bx * NBg + by) * NBg + bz; }
+static int g_layout = 0;     // 0: reference block order (bz fastest in memory); 1: x fastest in memory (an INTERNAL permutation the library could use)
+static int bid(int bx, int by, int bz) { return g_layout == 0 ? (bx * NBg + by) * NBg + bz : (bz * NBg + by) * NBg + bx; }
 
 // current product order: x-runs of 4, the 8 planes of a run on 8 consecutive workgroups, plane (x - bz) mod 8 on XCD x
 static Sched sched_current()
@@ -423,6 +426,20 @@ int main(int argc, char **argv)
         with("cur, all halos, 3 waves/SIMD", 4, ~0);
         with("cur, all halos (again)", 0, ~0);
     }
+    if (strchr(sel, '7')) {        // x-fastest internal block order: x-run schedules become memory-sequential
+        all.push_back(sched_current());
+        all.push_back(sched_natural(1));
+        g_layout = 1;
+        auto L1 = [&](Sched c, const char *tag) { c.name = std::string("[x-fastest layout] ") + tag; c.layout = 1; all.push_back(c); };
+        L1(sched_current(), "cur sweep (y fastest, x, z), 4x1 runs, rotated planes");
+        L1(sched_xrun("xyz", 0), "4x1 runs swept x fastest, then y, then z (memory order)");
+        L1(sched_xrun("xzy", 0), "4x1 runs swept x, z, y");
+        L1(sched_xrun("yxz", 0), "4x1 runs swept y, x, z");
+        L1(sched_xrun("xyYz", 4), "4x1 runs swept x, y inside tiles of 4, z");
+        L1(sched_natural(1), "natural (memory) order, 4 planes of a block per workgroup");
+        g_layout = 0;
+        all.push_back(sched_current());
+    }
     if (strchr(sel, '6')) {        // bricks in memory order: orders the product kernel can run as it is (LUDWIG_XRUN = waves per workgroup)
         all.push_back(sched_current());
         all.push_back(sched_pair16(2));
@@ -507,14 +524,14 @@ int main(int argc, char **argv)
                 CK(hipEventRecord(e0));
                 switch (s.nw) {
                 case 4:
-                    if (s.variant == 0) hipLaunchKernelGGL(k_march<4>, dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
-                    else if (s.variant == 1) hipLaunchKernelGGL((k_march<4, true, 0>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
-                    else if (s.variant == 2) hipLaunchKernelGGL((k_march<4, false, 5>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
-                    else if (s.variant == 3) hipLaunchKernelGGL((k_march<4, true, 5>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
-                    else hipLaunchKernelGGL((k_march<4, false, 3>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta);
+                    if (s.variant == 0) hipLaunchKernelGGL(k_march<4>, dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout);
+                    else if (s.variant == 1) hipLaunchKernelGGL((k_march<4, true, 0>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout);
+                    else if (s.variant == 2) hipLaunchKernelGGL((k_march<4, false, 5>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout);
+                    else if (s.variant == 3) hipLaunchKernelGGL((k_march<4, true, 5>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout);
+                    else hipLaunchKernelGGL((k_march<4, false, 3>), dim3(grid), dim3(256), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout);
                     break;
-                case 8: hipLaunchKernelGGL(k_march<8>, dim3(grid), dim3(512), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta); break;
-                case 16: hipLaunchKernelGGL(k_march<16>, dim3(grid), dim3(1024), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta); break;
+                case 8: hipLaunchKernelGGL(k_march<8>, dim3(grid), dim3(512), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout); break;
+                case 16: hipLaunchKernelGGL(k_march<16>, dim3(grid), dim3(1024), 0, 0, fin, fout, vin, vout, rho, d, s.niter, sk, NB, mask, d_meta, s.layout); break;
                 default: printf("bad nw\n"); return 1;
                 }
                 CK(hipEventRecord(e1));
