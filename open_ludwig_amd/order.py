@@ -217,6 +217,8 @@ BUILDERS = {
     "brick_2x1x4": lambda c: brick(c, 2, 1, 4),
     "brick_4x1x2": lambda c: brick(c, 4, 1, 2),
     "brick_2x2x2": lambda c: brick(c, 2, 2, 2),
+    "w8_8x1_xyz": lambda c: plane_per_xcd_rot_w8(c, 8, 1, "xyz"),
+    "w8_4x2_xyz": lambda c: plane_per_xcd_rot_w8(c, 4, 2, "xyz"),
     "w8_4x2_yxz": lambda c: plane_per_xcd_rot_w8(c, 4, 2, "yxz"),
     "w8_8x1_yxz": lambda c: plane_per_xcd_rot_w8(c, 8, 1, "yxz"),
     "w8_2x4_yxz": lambda c: plane_per_xcd_rot_w8(c, 2, 4, "yxz"),
