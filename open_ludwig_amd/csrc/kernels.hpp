@@ -9,10 +9,10 @@
 // (x*1 = x, x*-1 = -x exactly; a dropped x*0 term only changes the sign of an exact zero).
 //
 // Mapping: one 64-lane wavefront = one 8x8 z-plane of one 8^3 block (lane = x + 8y); a 256-thread
-// workgroup = 4 such planes chosen by the host's work list (by default the same plane of 2x2 x/y-adjacent
-// blocks, see ludwig_hip.hip). The block index and z are wave-uniform, so the 27 neighbour
-// block ids come through the scalar cache and each population load is one coalesced 256-B access
-// (plus the face/edge lanes that reach into a neighbour block).
+// workgroup = 4 such planes chosen by the host's work list (by default the same plane of 4 x-consecutive
+// blocks, which the library keeps consecutive in memory, see ludwig_hip.hip "Block order"). The block index and z
+// are wave-uniform, so the 27 neighbour block ids come through the scalar cache and each population load is one
+// coalesced, aligned 256-B access; the +-1 shift in x is a lane shift plus an LDS column between neighbouring waves.
 #pragma once
 
 #include <hip/hip_runtime.h>
