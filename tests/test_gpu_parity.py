@@ -390,3 +390,38 @@ def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
     assert not np.array_equal(devc[1].download("f"), got)
     for d in dev + devb + devc:
         d.close()
+
+
+def test_reference_behaviour_switches_give_the_same_bits(gpu, tmp_path):
+    """The three places where the library deliberately does something else than the reference's arrays suggest - its own block
+    order in device memory, one HIP stream per level inside a batch, the elided rho store - each have a switch back
+    (LUDWIG_REFERENCE_BLOCK_ORDER, LUDWIG_BATCH_SERIAL, LUDWIG_EAGER_RHO). With all three set, in a fresh process, a 3-level
+    wall-model tunnel gives exactly the fields of the default mode (and both equal the oracle's)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\\n"
+            "from open_ludwig_amd import adapt, cases, execute_timestep_batch\\n"
+            "g, p = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)\\n"
+            "d = [adapt(x, 0) for x in g]\\n"
+            "assert np.array_equal(d[0].block_order(), np.arange(g[0].n_blocks))\\n"
+            "execute_timestep_batch(d, 1, 5, np.float32(0.05), p)\\n"
+            "np.savez(sys.argv[1], **{f'{n}{i}': x.download(n) for i, x in enumerate(d) for n in ('f', 'f_temp', 'vel', 'vel_temp', 'rho')})\\n" % root)
+    out = str(tmp_path / "ref_mode.npz")
+    env = dict(os.environ, LUDWIG_REFERENCE_BLOCK_ORDER="1", LUDWIG_BATCH_SERIAL="1", LUDWIG_EAGER_RHO="1")
+    subprocess.run([sys.executable, "-c", code.replace("\\n", "\n"), out], check=True, env=env)
+    ref = np.load(out)
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)
+    dev = [adapt(g, 0) for g in grids]
+    assert not np.array_equal(dev[0].block_order(), np.arange(grids[0].n_blocks))
+    execute_timestep_batch(dev, 1, 5, np.float32(0.05), params)
+    oracle.execute_timestep_batch(grids, 1, 5, np.float32(0.05), params)
+    for i, (d, g) in enumerate(zip(dev, grids)):
+        for n in ("f", "f_temp", "vel", "vel_temp", "rho"):
+            a = d.download(n)
+            assert np.array_equal(a, ref[f"{n}{i}"]), (i, n)
+        fn, vn = oracle.newest_buffers(i, 5)
+        for n in (fn, vn, "rho"):
+            assert np.array_equal(d.download(n), getattr(g, n)), (i, n)
+        d.close()
