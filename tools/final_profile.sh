@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-tools/marchbench 32 9 4 > $O/floor.txt 2>&1
+tools/marchbench 32 9 47 > $O/floor.txt 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/trace -o t --output-format csv -- python3 bench.py --steps 100 --warmup 10 --cpu-seconds 0 > $O/bench_under_rocprof.json 2> $O/trace.err
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o p --output-format csv -- python3 tools/profile_step.py 256 12 > $O/pmc_fetch.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o p --output-format csv -- python3 tools/profile_step.py 256 12 > $O/pmc_write.log 2>&1
@@ -15,4 +15,6 @@ python3 tools/summarize_profile.py $O/trace $O $O/r02_bench256 16777216 > $O/sum
 cp $O/trace/t_kernel_stats.csv $O/r02_bench256_rocprofv3_kernel_stats.csv
 rm -rf $O/trace/t_kernel_trace.csv $O/pmc_fetch/*kernel_trace.csv $O/pmc_write/*kernel_trace.csv
 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 > $O/bench_again.json 2>> $O/bench.err
+LUDWIG_REFERENCE_BLOCK_ORDER=1 python bench.py --steps 100 --warmup 10 --cpu-seconds 0 > $O/bench_reference_block_order.json 2>> $O/bench.err
+python bench.py --size 512 --steps 30 --warmup 5 --cpu-seconds 0 > $O/bench512.json 2>> $O/bench.err
 cat $O/bench.json; cat $O/bench_under_rocprof.json; cat $O/floor.txt; cat $O/summary.txt
