@@ -97,6 +97,13 @@ copy_to_old!(d::DeviceLevel, timestep::Integer) = check(ccall((:ludwig_save_old,
 
 synchronize(d::DeviceLevel) = check(ccall((:ludwig_sync, LIB), Cint, (Ptr{Cvoid},), d.handle))
 
+"""compute_flow_stats(level).rho_min (src/diagnostics.jl:56-94), reduced on the device."""
+function rho_min(d::DeviceLevel)
+    v = Ref{Cfloat}(0)
+    check(ccall((:ludwig_level_rho_min, LIB), Cint, (Ptr{Cvoid}, Ref{Cfloat}), d.handle, v))
+    return v[]
+end
+
 """
 recursive_step! with the device calls swapped (src/solver_control.jl:21-143): same order, same parity, same weights.
 """
