@@ -78,7 +78,8 @@ def test_oracle_itself_reproduces_reference_cd_series(gpu, ball_setup):
     digits. The same loop on the HIP path must give the SAME rows, bit for bit (wall model included: shared jl_math.h).
     Step 200: the oracle / HIP give Cd 0.0637, the log prints 0.0633. profiles/r02_step200_fma_contraction_experiment.txt
     shows why: the same oracle source built with -ffp-contract=fast (the log is a CUDA run, NVPTX fuses a*b+c) gives
-    0.063311 at step 200 and the identical 0.145033 at step 400 - the difference is FMA contraction acting on forces of
+    0.063311 at step 200 and the identical 0.145033 at step 400 (and 0.074350 against the kept forces.csv's 0.074373 for the
+    4-level case, where the parity build gives 0.074838) - the difference is FMA contraction acting on forces of
     O(rho - 1) ~ 1e-5 in the first instants of the ramp, not a difference of algorithm."""
     from _steppers import OracleStepper
     from oracle import oracle
