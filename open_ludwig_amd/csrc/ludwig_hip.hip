@@ -1287,8 +1287,10 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
 //     interface pass has read them (ev_consumed, recorded on the child's stream right after that pass).
 // Launches are still issued in the reference's order; the GPU then runs level 1's step t + 1 under the finer levels' sub-steps
 // of step t, and a middle level's second sub-step under its children's first pair. Same kernels, same inputs: same bits.
-// LUDWIG_BATCH_SERIAL=1 keeps everything on one stream.
-static bool level_streams() { static const bool v = getenv("LUDWIG_BATCH_SERIAL") == nullptr; return v; }
+// Measured (profiles/r02_level_streams_speed.txt, r02_interface_prefetch_experiment.txt): -3 % / -6 % / +3 % on one box, +8 % / +1 % / -2 %
+// on another for the 3-level sphere / the wing / the 4-level sphere - a launch of a few thousand workgroups already fills the GPU, a
+// second kernel only shares it. So this is OFF by default; LUDWIG_LEVEL_STREAMS=1 turns it on.
+static bool level_streams() { static const bool v = getenv("LUDWIG_LEVEL_STREAMS") != nullptr; return v; }
 
 static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-based*/, int64_t t_sub, const LudwigLevel *parent,
                           float parent_tau, float temporal_weight, float u_vel, const LudwigStepFlags *fl, bool concurrent)
