@@ -126,6 +126,24 @@ def brick(coords, px: int, py: int, pz: int, rotate: bool = True) -> np.ndarray:
     return np.asarray(out, dtype=np.int32)
 
 
+def run_per_xcd(coords, rotate: bool = True) -> np.ndarray:
+    """x-runs of 4 in the sweep x, y, z, but the 8 planes of a run all on ONE XCD (run g -> XCD g % 8), start plane rotated by the XCD:
+    workgroup 64 s + 8 j + x = plane (j + x) % 8 of run 8 s + x. Full boxes with nbx % 4 == 0 and a multiple of 8 runs only (tools)."""
+    c = np.asarray(coords).astype(np.int64) - 1
+    nb = c.max(axis=0) + 1
+    lut = np.full(tuple(nb), -1, dtype=np.int64)
+    lut[c[:, 0], c[:, 1], c[:, 2]] = np.arange(len(c))
+    runs = [[int(lut[bx0 + w, by, bz]) for w in range(4)] for bz in range(nb[2]) for by in range(nb[1]) for bx0 in range(0, nb[0], 4)]
+    assert len(runs) % 8 == 0
+    out = []
+    for s0 in range(0, len(runs), 8):
+        for j in range(8):
+            for x in range(8):
+                z = (j + x) % 8 if rotate else j
+                out += [(b << 3) | z for b in runs[s0 + x]]
+    return np.asarray(out, dtype=np.int32)
+
+
 def plane_round_robin(coords, px: int = 2, py: int = 2, sweep: str = "xyz") -> np.ndarray:
     """same workgroups as plane_per_xcd but without aiming planes at XCDs: patch after patch, all 8 planes in turn,
     for each workgroup of a large patch -> isolates the effect of workgroup grouping from XCD placement"""
@@ -217,6 +235,8 @@ BUILDERS = {
     "brick_2x1x4": lambda c: brick(c, 2, 1, 4),
     "brick_4x1x2": lambda c: brick(c, 4, 1, 2),
     "brick_2x2x2": lambda c: brick(c, 2, 2, 2),
+    "run_per_xcd": lambda c: run_per_xcd(c, True),
+    "run_per_xcd_norot": lambda c: run_per_xcd(c, False),
     "w8_8x1_xyz": lambda c: plane_per_xcd_rot_w8(c, 8, 1, "xyz"),
     "w8_4x2_xyz": lambda c: plane_per_xcd_rot_w8(c, 4, 2, "xyz"),
     "w8_4x2_yxz": lambda c: plane_per_xcd_rot_w8(c, 4, 2, "yxz"),

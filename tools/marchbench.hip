@@ -39,6 +39,7 @@ void k_march(const float *__restrict__ fin, float *__restrict__ fout, const floa
         if (raw < 0) continue;
         const int fl = raw & mask;
         const int id = raw & ID_MASK, b = id >> 3, z = id & 7;
+        const bool aosoa = layout == 2;            // block-major: the 27 populations of a block are contiguous (f[block][k][512])
         const int bz = layout == 0 ? b % NB : b / (NB * NB), by = (b / NB) % NB, bx = layout == 0 ? b / (NB * NB) : b % NB;
         int nbm[27];
         if (DEP) {     // as the product: the 27 neighbour ids come from a per-block row, a scalar load that depends on the item
@@ -56,13 +57,14 @@ void k_march(const float *__restrict__ fin, float *__restrict__ fout, const floa
             const int cz = k / 9 - 1;
             const int sz = z - cz;
             const uint32_t nb = blk(0, 0, sz < 0 ? -1 : sz > 7 ? 1 : 0);
-            v[k] = ldf(fin + sk * k, (nb * 512u + 64 * (sz & 7) + lane) * 4u);
+            v[k] = aosoa ? ldf(fin, ((nb * 27u + k) * 512u + 64 * (sz & 7) + lane) * 4u) : ldf(fin + sk * k, (nb * 512u + 64 * (sz & 7) + lane) * 4u);
         }
         const uint32_t own = ((uint32_t)b * 512u + z * 64u + lane) * 4u;
+        const uint32_t ownA = ((uint32_t)b * 27u * 512u + z * 64u + lane) * 4u, ownV = ((uint32_t)b * 3u * 512u + z * 64u + lane) * 4u;
         // velocity planes: centre / below / above (in a marching design most of them are already in registers)
         if (fl & F_C) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) uc[c] = ldf(vin + sk * c, own);
+            for (int c = 0; c < 3; ++c) uc[c] = aosoa ? ldf(vin, ownV + c * 2048u) : ldf(vin + sk * c, own);
         }
         if (fl & F_B) {
             const uint32_t o = (blk(0, 0, z == 0 ? -1 : 0) * 512u + 64 * ((z - 1) & 7) + lane) * 4u;
@@ -105,9 +107,9 @@ void k_march(const float *__restrict__ fin, float *__restrict__ fout, const floa
             for (int c = 0; c < 3; ++c) h += ldf(vin + sk * c, (blk(0, 1, 0) * 512u + 64 * z + 8 * 0 + x) * 4u);
         }
 #pragma unroll
-        for (int k = 0; k < Q; ++k) stf(fout + sk * k, own, v[k] + h);
+        for (int k = 0; k < Q; ++k) { if (aosoa) stf(fout, ownA + k * 2048u, v[k] + h); else stf(fout + sk * k, own, v[k] + h); }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) stf(vout + sk * c, own, uc[c] + ub[c] + ut[c]);
+        for (int c = 0; c < 3; ++c) { if (aosoa) stf(vout, ownV + c * 2048u, uc[c] + ub[c] + ut[c]); else stf(vout + sk * c, own, uc[c] + ub[c] + ut[c]); }
         stf(rho, own, v[0] + uc[0]);
         // march: the plane above becomes the centre, the centre the plane below
 #pragma unroll
@@ -126,7 +128,7 @@ struct Sched {
 
 static int NBg = 32;
 static int g_layout = 0;     // 0: reference block order (bz fastest in memory); 1: x fastest in memory (an INTERNAL permutation the library could use)
-static int bid(int bx, int by, int bz) { return g_layout == 0 ? (bx * NBg + by) * NBg + bz : (bz * NBg + by) * NBg + bx; }
+static int bid(int bx, int by, int bz) { return g_layout == 0 ? (bx * NBg + by) * NBg + bz : (bz * NBg + by) * NBg + bx; }   // 1, 2: x fastest
 
 // current product order: x-runs of 4, the 8 planes of a run on 8 consecutive workgroups, plane (x - bz) mod 8 on XCD x
 static Sched sched_current()
@@ -350,6 +352,32 @@ static Sched sched_brick(int PX, int PY, int PZ, bool rotate)
     return s;
 }
 
+
+// x-run groups in memory order (x-fastest layout), but the 8 planes of a group all on ONE XCD (group g -> XCD g % 8), taken in turn
+// with a start plane rotated by the XCD: workgroup 64 s + 8 j + x = plane (j + x) % 8 of group 8 s + x. The z+-1 velocity planes
+// and the y neighbour group (8 groups on) then meet in the same L2; the x neighbour group does not.
+static Sched sched_xrun_group_per_xcd(bool rotate)
+{
+    Sched s{rotate ? "4x1 runs in memory order, the 8 planes of a run on ONE XCD, start plane rotated" : "4x1 runs in memory order, the 8 planes of a run on ONE XCD", 4, 1, {}};
+    const int NB = NBg;
+    struct G { int bx0, by, bz; };
+    std::vector<G> gs;
+    for (int bz = 0; bz < NB; ++bz) for (int by = 0; by < NB; ++by) for (int bx0 = 0; bx0 < NB; bx0 += 4) gs.push_back({bx0, by, bz});
+    for (size_t s0 = 0; s0 < gs.size(); s0 += 8)
+        for (int j = 0; j < 8; ++j)
+            for (int x = 0; x < 8; ++x) {
+                const G &g = gs[s0 + x];
+                const int z = rotate ? (j + x) % 8 : j;
+                for (int w = 0; w < 4; ++w) {
+                    int fl = F_C | F_B | F_T | F_S | F_N;
+                    if (w == 0) fl |= F_W;
+                    if (w == 3) fl |= F_E;
+                    s.items.push_back(((bid(g.bx0 + w, g.by, g.bz) << 3) | z) | fl);
+                }
+            }
+    return s;
+}
+
 // natural: block order, 4 consecutive planes per workgroup, nothing shared
 static Sched sched_natural(int niter)
 {
@@ -425,6 +453,24 @@ int main(int argc, char **argv)
         with("cur, all halos, dependent load + 5 waves/SIMD", 3, ~0);
         with("cur, all halos, 3 waves/SIMD", 4, ~0);
         with("cur, all halos (again)", 0, ~0);
+    }
+    if (strchr(sel, '9')) {
+        g_layout = 1;
+        { Sched c = sched_xrun("xyz", 0); c.name = "[x-fastest layout] 4x1 runs swept x, y, z, planes of a run spread over the 8 XCDs (product)"; c.layout = 1; all.push_back(c); }
+        { Sched c = sched_xrun_group_per_xcd(true); c.layout = 1; all.push_back(c); }
+        { Sched c = sched_xrun_group_per_xcd(false); c.layout = 1; all.push_back(c); }
+        { Sched c = sched_natural(1); c.name = "[x-fastest layout] memory order, 4 planes of a block per workgroup"; c.layout = 1; all.push_back(c); }
+        { Sched c = sched_xrun("xyz", 0); c.name = "[x-fastest layout] 4x1 runs swept x, y, z, planes of a run spread over the 8 XCDs (product)"; c.layout = 1; all.push_back(c); }
+        g_layout = 0;
+    }
+    if (strchr(sel, '8')) {        // block-major storage (all 27 populations of a block contiguous) on top of the x-fastest block order; floor only
+        g_layout = 1;
+        { Sched c = sched_xrun("xyz", 0); c.name = "[x-fastest layout, population-major] 4x1 runs swept x, y, z"; c.layout = 1; all.push_back(c); }
+        { Sched c = sched_xrun("xyz", 0); c.name = "[x-fastest layout, BLOCK-major f[b][k][512]] 4x1 runs swept x, y, z (floor column only)"; c.layout = 2; c.halo_mask = F_C; all.push_back(c); }
+        { Sched c = sched_natural(1); c.name = "[x-fastest layout, population-major] memory order, 4 planes per workgroup"; c.layout = 1; c.halo_mask = F_C; all.push_back(c); }
+        { Sched c = sched_natural(1); c.name = "[x-fastest layout, BLOCK-major] memory order, 4 planes per workgroup (floor column only)"; c.layout = 2; c.halo_mask = F_C; all.push_back(c); }
+        { Sched c = sched_xrun("xyz", 0); c.name = "[x-fastest layout, population-major] 4x1 runs swept x, y, z"; c.layout = 1; all.push_back(c); }
+        g_layout = 0;
     }
     if (strchr(sel, '7')) {        // x-fastest internal block order: x-run schedules become memory-sequential
         all.push_back(sched_current());
