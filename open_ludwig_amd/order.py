@@ -128,19 +128,18 @@ def brick(coords, px: int, py: int, pz: int, rotate: bool = True) -> np.ndarray:
 
 def run_per_xcd(coords, rotate: bool = True) -> np.ndarray:
     """x-runs of 4 in the sweep x, y, z, but the 8 planes of a run all on ONE XCD (run g -> XCD g % 8), start plane rotated by the XCD:
-    workgroup 64 s + 8 j + x = plane (j + x) % 8 of run 8 s + x. Full boxes with nbx % 4 == 0 and a multiple of 8 runs only (tools)."""
+    workgroup 64 s + 8 j + x = plane (j + x) % 8 of run 8 s + x. Full boxes with nbx % 4 == 0 only (tools)."""
     c = np.asarray(coords).astype(np.int64) - 1
     nb = c.max(axis=0) + 1
     lut = np.full(tuple(nb), -1, dtype=np.int64)
     lut[c[:, 0], c[:, 1], c[:, 2]] = np.arange(len(c))
     runs = [[int(lut[bx0 + w, by, bz]) for w in range(4)] for bz in range(nb[2]) for by in range(nb[1]) for bx0 in range(0, nb[0], 4)]
-    assert len(runs) % 8 == 0
     out = []
     for s0 in range(0, len(runs), 8):
         for j in range(8):
             for x in range(8):
                 z = (j + x) % 8 if rotate else j
-                out += [(b << 3) | z for b in runs[s0 + x]]
+                out += [(b << 3) | z for b in runs[s0 + x]] if s0 + x < len(runs) else [-1] * 4     # idle workgroup: keeps the XCD slots
     return np.asarray(out, dtype=np.int32)
 
 
