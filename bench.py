@@ -12,6 +12,10 @@ Prints ONE JSON line (rank 0). `roofline` prices the stream-collide kernel again
 algorithmic 216 B per lattice update; `cpu_baseline` is the CPU oracle (a port, NOT the reference's Julia CPU
 path, which cannot run here) timed on a bounded 64^3 sample of the same workload.
 
+Before the W warm-up steps the device is kept busy for --preheat-ms (default 60 ms) with plain device-to-device copies of two
+scratch buffers - no stepping - because the step time shows a 25-step power-management transient after any idle period and the set-up
+leaves the device idle; `config.device_preheat_ms` reports it, `--preheat-ms 0` turns it off.
+
 `roofline.traffic` comes from rocprofv3 PMC passes, which cannot run inside this process: it is read from
 profiles/traffic.json and reported ONLY if that file was captured with the very sources the loaded library was built from
 (`source_digest`) on the same workload size; otherwise it is null and `traffic_source` says why. Capture: tools/final_profile.sh.
