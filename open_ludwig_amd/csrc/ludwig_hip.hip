@@ -1287,10 +1287,12 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
 //     interface pass has read them (ev_consumed, recorded on the child's stream right after that pass).
 // Launches are still issued in the reference's order; the GPU then runs level 1's step t + 1 under the finer levels' sub-steps
 // of step t, and a middle level's second sub-step under its children's first pair. Same kernels, same inputs: same bits.
-// Measured (profiles/r02_level_streams_speed.txt, r02_interface_prefetch_experiment.txt): -3 % / -6 % / +3 % on one box, +8 % / +1 % / -2 %
-// on another for the 3-level sphere / the wing / the 4-level sphere - a launch of a few thousand workgroups already fills the GPU, a
-// second kernel only shares it. So this is OFF by default; LUDWIG_LEVEL_STREAMS=1 turns it on.
-static bool level_streams() { static const bool v = getenv("LUDWIG_LEVEL_STREAMS") != nullptr; return v; }
+// The finest level is the critical chain (2^(n-1) sub-steps per coarse step): its stream gets the highest priority, the others the
+// lowest, so the coarser levels only fill what it leaves free. Measured on one box, alternating (profiles/
+// r02_level_streams_with_priorities_ab_one_box.txt): 3-level sphere 0.419 -> 0.393 ms per coarse step, real wing 1.011 -> 0.949,
+// 4-level sphere 1.72 -> 1.52; without the priorities 0.402 / 0.982 / 1.58 (and on another box the 4-level case got slower).
+// LUDWIG_BATCH_SERIAL=1 keeps everything on one stream; LUDWIG_LEVEL_STREAM_PRIORITY=0 gives every level the same priority.
+static bool level_streams() { static const bool v = getenv("LUDWIG_BATCH_SERIAL") == nullptr; return v; }
 
 static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-based*/, int64_t t_sub, const LudwigLevel *parent,
                           float parent_tau, float temporal_weight, float u_vel, const LudwigStepFlags *fl, bool concurrent)
@@ -1332,7 +1334,14 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
         for (int i = 0; i < n_levels; ++i) {
             LudwigLevel *L = levels[i];
             if (!L->own_stream) {
-                LW_HIP(hipStreamCreateWithFlags(&L->own_stream, hipStreamNonBlocking));
+                // the finest level is the critical chain (2^(n-1) sub-steps per coarse step): its stream gets the highest priority, the
+                // coarser levels fill what it leaves free
+                int pr_least = 0, pr_greatest = 0;
+                LW_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+                const char *pe = getenv("LUDWIG_LEVEL_STREAM_PRIORITY");
+                const bool use_pr = !pe || atoi(pe) != 0;
+                const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);
+                LW_HIP(hipStreamCreateWithPriority(&L->own_stream, hipStreamNonBlocking, pr));
                 LW_HIP(hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming));
                 LW_HIP(hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming));
             }
