@@ -1340,7 +1340,7 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
                 LW_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
                 const char *pe = getenv("LUDWIG_LEVEL_STREAM_PRIORITY");
                 const bool use_pr = !pe || atoi(pe) != 0;
-                const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);
+                const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);   // graded priorities: no better
                 LW_HIP(hipStreamCreateWithPriority(&L->own_stream, hipStreamNonBlocking, pr));
                 LW_HIP(hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming));
                 LW_HIP(hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming));
