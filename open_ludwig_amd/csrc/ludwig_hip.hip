@@ -19,7 +19,6 @@ using namespace lw;
 namespace {
 
 thread_local std::string g_err;
-thread_local bool g_creating_permuted = false;   // ludwig_level_create -> level_create_impl: the description is in internal order
 
 int fail(int code, const char *fmt, ...)
 {
@@ -848,7 +847,7 @@ void ludwig_level_destroy(LudwigLevel *L)
     delete L;
 }
 
-static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel **out);
+static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel **out, bool x_fastest_memory);
 
 int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
 {
@@ -856,7 +855,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     if (!h || !out) return fail(LUDWIG_ERR_INVALID, "null argument");
     const int32_t nb = h->n_blocks;
     if (nb <= 1 || getenv("LUDWIG_REFERENCE_BLOCK_ORDER") || !h->neighbor_table || !h->map_x || !h->map_y || !h->map_z)
-        return level_create_impl(h, device, out);
+        return level_create_impl(h, device, out, false);
     const int n_owned = h->n_owned > 0 ? h->n_owned : (h->n_owned < 0 ? 0 : nb);
     if (n_owned > nb) return fail(LUDWIG_ERR_INVALID, "n_owned > n_blocks");
     // internal order: owned blocks first (as given), inside each group sorted by (bz, by, bx) - bx fastest
@@ -921,9 +920,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
         }
         hp.block_pointer = bp.data();
     }
-    g_creating_permuted = true;
-    const int rc = level_create_impl(&hp, device, out);
-    g_creating_permuted = false;
+    const int rc = level_create_impl(&hp, device, out, true);   // the description is in the internal order now
     if (rc) return rc;
     LudwigLevel *L = *out;
     L->ref2int.swap(ref2int);
@@ -934,7 +931,7 @@ int ludwig_level_create(const LudwigLevelHost *h, int device, LudwigLevel **out)
     return LUDWIG_OK;
 }
 
-static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel **out)
+static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel **out, bool x_fastest_memory)
 {
     if (out) *out = nullptr;
     if (!h || !out) return fail(LUDWIG_ERR_INVALID, "null argument");
@@ -951,7 +948,7 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
     LudwigLevel *L = new (std::nothrow) LudwigLevel();
     if (!L) return fail(LUDWIG_ERR_ALLOC, "host allocation failed");
     L->device = device;
-    L->x_fastest_memory = g_creating_permuted;
+    L->x_fastest_memory = x_fastest_memory;
     L->level_id = h->level_id;
     L->n_blocks = h->n_blocks;
     L->n_owned = n_owned;

@@ -8,12 +8,19 @@ The reference is single-device (F2); this module has no reference counterpart. D
     one-cell face layer and the three components of `vel_out` (WALE stencil). What exactly is read is DERIVED from
     the pull / stencil rules, cell by cell, into index lists ("needs"); the owner of each block serves them.
   * exchange = gather by index list -> one message per peer (RCCL send/recv, point-to-point over xGMI) -> scatter.
-    No collective on the data path. Boundary blocks are stepped first, so the exchange overlaps the interior update.
+    No collective on the data path. The exchange runs on a second HIP stream under compute: a single level (and the finest
+    of nested levels) steps its interior blocks - which read no ghost - first, under the exchange of the PREVIOUS step, then
+    its boundary blocks; a level with children steps its boundary blocks first and exchanges under its interior blocks,
+    because its children need the ghosts next. Levels with Bouzidi cells fit in: their small f_post halo is waited for
+    between the collision and the correction. The RCCL backend has never executed any of this (one-GPU boxes): rehearsed
+    over gloo with host staging, all ranks on one device.
 
   * nested levels (row N3): every level is cut on its own into equal parts (level_owners); a rank's copy of a level also
     holds ghost copies of the parent blocks its finer blocks interpolate from (required_parent_blocks), and the parent
     cells of those interface stencils join the parent level's needs (interpolation_needs). MultiLevelRunner repeats the
     reference's recursion with one exchange after every level step.
+  * diagnostics cross ranks as scalars only (case.DistributedStepper: rho_min by all-reduce MIN, nine partial force sums
+    per rank and one all-gather); whole fields are gathered on result-file steps, to rank 0.
 
 Pure-numpy planning (build_local_level, compute_needs, interpolation_needs, HaloPlan) is separate from transport
 (HaloExchanger) and from the GPU runners, so the N > 1 logic is covered by CPU tests over gloo.
