@@ -50,24 +50,32 @@ def test_setup_matches_reference_log(ball_setup):
     assert ((q >= 0) & (q <= 1)).all() and (q > 0).sum() > 5824
 
 
-def _log_series():
+def _log_series(late=False):
     rows = [l.strip().split(",") for l in open(os.path.join(G, "sphere_re266k_log.csv")) if l[0].isdigit()]
+    if late:
+        rows += [l.strip().split(",") for l in open(os.path.join(G, "sphere_re266k_log_late.csv")) if l[0].isdigit()]
     return {int(r[0]): [float(v) for v in r[1:]] for r in rows}
 
 
 @pytest.mark.gpu
 def test_hip_reproduces_reference_cd_series(gpu, ball_setup):
+    """The WHOLE run of the reference's log, all 30 rows to step 6000 (28.6 G cell updates, 2.8 s): the ramp (rows 200...2000) to the
+    printed 4 decimals, and the developed phase (rows 2200...6000), where a contracting CUDA run and this one could have
+    decorrelated but do not, within 8e-4 (observed <= 6e-4; profiles/r02_ball1m_re266k_6000_steps_vs_reference_log.txt). The log's
+    final summary (Cd 0.447263, Cl -0.120969 at step 6000) is met to 5e-4 / 6e-4."""
     cfg, setup = ball_setup
-    rows, _, _ = case.run_case(cfg, case.HipStepper, steps=2000, setup=pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl")))
-    log = _log_series()
+    rows, _, _ = case.run_case(cfg, case.HipStepper, steps=6000, setup=pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl")))
+    log = _log_series(late=True)
     got = {r.step: r for r in rows}
-    assert sorted(got) == sorted(log)
+    assert sorted(got) == sorted(log) and len(log) == 30
     for step, (u_lat, rho_min, cd, cl) in log.items():
         r = got[step]
         assert abs(r.u_lat - u_lat) <= 5.1e-5, step
         assert abs(r.rho_min - rho_min) <= 1.01e-4, (step, r.rho_min, rho_min)
-        assert abs(r.cd - cd) <= (5e-4 if step == 200 else 2.01e-4), (step, r.cd, cd)
-        assert abs(r.cl - cl) <= 2.01e-4, (step, r.cl, cl)
+        tol = 5e-4 if step == 200 else (2.01e-4 if step <= 2000 else 8e-4)
+        assert abs(r.cd - cd) <= tol, (step, r.cd, cd)
+        assert abs(r.cl - cl) <= tol, (step, r.cl, cl)
+    assert abs(got[6000].cd - 0.447263) <= 8e-4 and abs(got[6000].cl + 0.120969) <= 8e-4
 
 
 @pytest.mark.gpu
