@@ -244,30 +244,36 @@ def test_re10m_setup_matches_reference_log(ball_re10m_setup):
 @pytest.mark.gpu
 def test_hip_reproduces_reference_forces_csv_re10m(gpu, ball_re10m_setup, tmp_path):
     """The reference's kept forces.csv (CUDA run, FMA contraction, Float32 atomics) against this engine + forces + CSV
-    writer, steps 400...2000 of the ramp: drag force to 5e-4 relative (observed <= 3e-4, mostly ~5e-5), its viscous part to
-    1e-3, Cd to 1e-4 absolute, side/lift coefficients to 1e-4 absolute; physical time and inlet speed columns exactly."""
+    writer, steps 400...4000: drag force to 5e-4 relative (observed <= 3e-4, mostly ~5e-5), its viscous part to 1e-3, Cd to
+    1e-4 absolute during the ramp and 1.5e-4 after it, side / lift coefficients to 1e-4 / 2e-4; physical time and inlet speed columns
+    exactly. At this Reynolds number (tau_fine 0.500001) the two runs do separate in the end: 3.5e-4 at step 4200, 2.6e-3 at 4800,
+    1e-1 at 5800 (profiles/r02_ball1m_re10m_6000_steps_vs_reference_forces_csv.txt) - the chaotic divergence SURVEY section 4 predicted."""
     import copy
     cfg, setup = ball_re10m_setup
     cfg = copy.copy(cfg)
     cfg.output_freq = 10 ** 9                         # no VTU here: the flow file of 3.9 M cells is ~100 MB
-    rows, _, params = case.run_case(cfg, case.HipStepper, steps=2000, setup=setup, out_dir=str(tmp_path))
+    last = 4000
+    rows, _, params = case.run_case(cfg, case.HipStepper, steps=last, setup=setup, out_dir=str(tmp_path))
     ref = {int(l.split(",")[0]): l.strip().split(",") for l in open(os.path.join(G, "sphere_re10m_forces.csv")) if l[0].isdigit()}
     mine = {int(l.split(",")[0]): l.strip().split(",") for l in open(tmp_path / "forces.csv") if l[0].isdigit()}
-    assert sorted(mine) == list(range(200, 2001, 200))
-    for s in range(400, 2001, 200):
+    assert sorted(mine) == list(range(200, last + 1, 200))
+    for s in range(400, last + 1, 200):
         a, b = mine[s], ref[s]
         assert a[1] == b[1] and a[2] == b[2], "Time_s / U_inlet columns"
         fx, fxr = float(a[3]), float(b[3])
         assert abs(fx - fxr) <= 5e-4 * abs(fxr), (s, fx, fxr)
         assert abs(float(a[7]) - float(b[7])) <= 1e-3 * abs(float(b[7])), (s, "Fx_v")
-        for col in (11, 12, 13):                       # Cd, Cl, Cs
-            assert abs(float(a[col]) - float(b[col])) <= 1e-4, (s, col, a[col], b[col])
+        tol = 1e-4 if s <= 2000 else 2e-4
+        assert abs(float(a[11]) - float(b[11])) <= (1e-4 if s <= 2000 else 1.5e-4), (s, "Cd", a[11], b[11])
+        for col in (12, 13):                           # Cl, Cs
+            assert abs(float(a[col]) - float(b[col])) <= tol, (s, col, a[col], b[col])
     conv = {int(l.split(",")[0]): l.strip().split(",") for l in open(os.path.join(G, "sphere_re10m_convergence.csv")) if l[0].isdigit()}
     minec = {int(l.split(",")[0]): l.strip().split(",") for l in open(tmp_path / "convergence.csv") if l[0].isdigit()}
-    for s in range(400, 2001, 200):
+    for s in range(400, last + 1, 200):
         assert minec[s][2] == conv[s][2] and minec[s][3] == conv[s][3], "Time_phys_s / U_inlet_lat text"
-        assert abs(float(minec[s][4]) - float(conv[s][4])) <= 2e-6, "rho_min"
-        assert abs(float(minec[s][6]) - float(conv[s][6])) <= 1.5e-4 and abs(float(minec[s][7]) - float(conv[s][7])) <= 1.5e-4
+        assert abs(float(minec[s][4]) - float(conv[s][4])) <= (2e-6 if s <= 2000 else 2e-5), ("rho_min", s, minec[s][4], conv[s][4])
+        ctol = 1.5e-4 if s <= 2000 else 2.5e-4
+        assert abs(float(minec[s][6]) - float(conv[s][6])) <= ctol and abs(float(minec[s][7]) - float(conv[s][7])) <= ctol, (s, minec[s], conv[s])
 
 
 # ---- third log: same mesh at Re 986 667 (velocity 14.8 m/s) ----
