@@ -17,7 +17,7 @@
  * 0.0637 here, 0.0633 in the log) is reproduced by building this same source with FMA contraction,
  * as the reference's CUDA run was (tools/oracle_contraction.py: 0.063311); (ii) the force / convergence histories the reference keeps
  * under CASES/ball1m/RESULTS (Re 9.87 M, 4 levels): the HIP path, which is bit-identical to
- * this oracle, reproduces them to 1e-5..3e-4 relative in the drag force over 3000 steps;
+ * this oracle, reproduces them to 1e-5..3e-4 relative in the drag force over 4000 steps;
  * (iii) analytic invariants and bit-level re-derivations (tests/test_oracle_invariants.py).
  * One piece of arithmetic is SHARED with the product: open_ludwig_amd/csrc/jl_math.h (double log2 /
  * exp2 / log from IEEE +,-,*,/ only, used by the wall model), compiled into both so that wall-model
