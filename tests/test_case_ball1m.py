@@ -280,18 +280,22 @@ def test_hip_reproduces_reference_forces_csv_re10m(gpu, ball_re10m_setup, tmp_pa
 @pytest.mark.gpu
 def test_hip_reproduces_reference_cd_series_re1m(gpu):
     """RESULTS_SPHERE_RE1M.txt: the 3-level mesh of the Re 266 k run at 3.7x the speed (tau_fine 0.500002). Cd / Cl / rho_min
-    of steps 200...2000 (the ramp) to the log's 4 printed decimals (+-2 in the last digit; the log is a CUDA run), 2200...3000
-    within 1e-3."""
+    of steps 200...2000 (the ramp) to the log's 4 printed decimals (+-2 in the last digit; the log is a CUDA run), 2200...6000
+    (the first two shedding cycles) within 1e-3; observed 6.7e-4. Past step ~7200 the two runs decorrelate - the whole 12 000-step
+    table is profiles/r02_ball1m_re1m_12000_steps_vs_reference_log.txt."""
     cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"),
                                      {"basic": {"surface_resolution": 25, "num_levels": 3, "flow": {"velocity": 14.8}}})
     setup = pp.setup_multilevel_domain(cfg, os.path.join(G, "ball1m.stl"))
     assert [f"{float(t):.6f}" for t in setup[2].tau_levels] == ["0.500009", "0.500005", "0.500002"]      # log line 103
     assert "%.2f" % np.float32(setup[2].rho_physical * setup[2].velocity_scale ** 2) == "298137.78"      # log line 162 (Float32)
     cfg.diag_freq = 200
-    rows, _, _ = case.run_case(cfg, case.HipStepper, steps=3000, setup=setup)
-    log = {int(l.split(",")[0]): [float(v) for v in l.split(",")[1:]] for l in open(os.path.join(G, "sphere_re1m_log.csv")) if l[0].isdigit()}
+    rows, _, _ = case.run_case(cfg, case.HipStepper, steps=6000, setup=setup)
+    log = {}
+    for name in ("sphere_re1m_log.csv", "sphere_re1m_log_late.csv"):
+        log.update({int(l.split(",")[0]): [float(v) for v in l.split(",")[1:]] for l in open(os.path.join(G, name)) if l[0].isdigit()})
+    log = {s: v for s, v in log.items() if s <= 6000}
     got = {r.step: r for r in rows}
-    assert sorted(got) == sorted(log) and len(log) == 15
+    assert sorted(got) == sorted(log) and len(log) == 30
     for step, (u_lat, rho_min, cd, cl) in log.items():
         r = got[step]
         assert abs(r.u_lat - u_lat) <= 5.1e-5 and abs(r.rho_min - rho_min) <= 1.01e-4, step
