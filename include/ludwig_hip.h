@@ -124,6 +124,17 @@ void ludwig_level_destroy(LudwigLevel *level);
 int  ludwig_level_set_stream(LudwigLevel *level, void *hip_stream);
 
 /*
+ * A HIP stream whose kernels may use every compute unit of `device` except `reserved_cus` of them (0 = an ordinary stream).
+ * For the multi-GPU schedule: the interior blocks of step t + 1 run while the halo of step t travels (ludwig_halo_pack, RCCL
+ * send/recv, ludwig_halo_unpack on other streams). A stream-collide launch fills every CU, and a send/recv kernel queued beside
+ * it - even on a high-priority stream - is handed its workgroups only as the launch drains (measured: 20 us alone, 470 us beside
+ * it). Compute units the stepping stream never uses are free the moment the exchange needs them; the step is HBM-bound and does
+ * not miss them. The reserved CUs are spread evenly over the XCDs. No reference counterpart (single GPU); hipStream_t in *stream_out.
+ */
+int  ludwig_stream_create(int device, int reserved_cus, void **stream_out);
+int  ludwig_stream_destroy(int device, void *hip_stream);
+
+/*
  * Launch order of the stream-collide kernel. One item per WAVE: items[i] = (block0 << 3) | z with block0 0-based
  * and z in 0..7 = the 8x8 z-plane of that block the wave steps; a negative item is an idle wave. Every
  * (block, plane) of the part must appear exactly once. Purely a performance knob (L2 / Infinity-Cache

@@ -105,6 +105,17 @@ function rho_min(d::DeviceLevel)
 end
 
 """
+Multi-GPU hosts only: a HIP stream for the stepping kernels that leaves `reserved_cus` compute units to the halo exchange
+(`ludwig_stream_create`, include/ludwig_hip.h); hand it to `ludwig_level_set_stream`. No counterpart in the reference.
+"""
+function stream_create(device::Integer, reserved_cus::Integer)
+    s = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:ludwig_stream_create, LIB), Cint, (Cint, Cint, Ref{Ptr{Cvoid}}), Cint(device), Cint(reserved_cus), s))
+    return s[]
+end
+stream_destroy(device::Integer, s::Ptr{Cvoid}) = check(ccall((:ludwig_stream_destroy, LIB), Cint, (Cint, Ptr{Cvoid}), Cint(device), s))
+
+"""
 recursive_step! with the device calls swapped (src/solver_control.jl:21-143): same order, same parity, same weights.
 """
 function recursive_step!(grids::Vector{DeviceLevel}, lvl::Int, t_sub::Int, parent, parent_tau::Float32, tw::Float32,

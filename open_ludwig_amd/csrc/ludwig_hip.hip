@@ -116,13 +116,15 @@ struct LudwigLevel {
     // for it (now and then). A level nobody has read `rho` of in between therefore skips the store and remembers the
     // launch (rho_replay); ensure_rho() reproduces the array on demand with the RHO_ONLY instantiation, from the same
     // input buffers (a pull step never writes its inputs) - bit for bit what the step would have stored.
+    // Only whole-level launches (LUDWIG_PART_ALL) elide the store. Boundary / interior part launches - the multi-GPU schedule, where
+    // the next step's interior blocks start before this step's halo has landed - always store: a part's elided rho could no longer
+    // be reproduced once another part's launch has reused its input buffer.
     bool rho_eager = false;             // a child reads rho after every step (or LUDWIG_EAGER_RHO): always store
     struct RhoReplay {
-        bool stale = false;             // the launch of this part left rho unwritten
-        bool lost = false;              // ... and a later launch of ANOTHER part has since overwritten its input buffer
+        bool stale = false;             // the launch left rho unwritten
         int64_t t_sub = -1;
         SCParams p;
-    } rho_replay[N_PARTS];
+    } rho_replay[N_PARTS];              // only [LUDWIG_PART_ALL] is ever stale
     int64_t step_count = 0, last_step_t = -1, last_replay_step = -10;   // a level asked for rho after two steps in a row turns eager
     // ludwig_execute_timestep_batch runs every level on a stream of its own (level_streams below): events that order them
     hipStream_t own_stream = nullptr;
@@ -611,21 +613,15 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     {
         static const bool eager_env = getenv("LUDWIG_EAGER_RHO") != nullptr || getenv("LUDWIG_NO_XRUN") != nullptr;
         if (t_sub != L->last_step_t) { ++L->step_count; L->last_step_t = t_sub; }
-        const bool store = L->rho_eager || eager_env;
-        // whole-level launches and part launches do not mix in one bookkeeping: settle the other kind first
+        const bool store = L->rho_eager || eager_env || part != LUDWIG_PART_ALL;
+        // This launch reuses the previous step's INPUT buffer as its output. A whole-level launch supersedes the elided rho of
+        // the previous one (the reference would be overwriting it right now, unread); a part launch covers only some of the
+        // cells, so the rest is produced first, while its inputs still exist.
         if (part != LUDWIG_PART_ALL && L->rho_replay[LUDWIG_PART_ALL].stale) {
             const int r = ensure_rho(L);
             if (r) return r;
         }
-        // This launch reuses the previous step's INPUT buffer as its output. An elided rho of the cells it covers is simply
-        // superseded (the reference would be overwriting it right now, unread); an elided rho of another part can no longer
-        // be produced once its inputs are gone: it is marked lost, and asking for it is an error instead of a wrong answer.
-        for (int a = 0; a < N_PARTS; ++a) {
-            LudwigLevel::RhoReplay &rr = L->rho_replay[a];
-            if (!rr.stale) continue;
-            if (a == part || part == LUDWIG_PART_ALL) rr.stale = rr.lost = false;
-            else if (rr.t_sub != t_sub) rr.lost = true;
-        }
+        L->rho_replay[LUDWIG_PART_ALL].stale = false;
         p.store_rho = store ? 1 : 0;
     }
 
@@ -701,7 +697,6 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     if (!p.store_rho) {
         LudwigLevel::RhoReplay &rr = L->rho_replay[part];
         rr.stale = true;
-        rr.lost = false;
         rr.t_sub = t_sub;
         rr.p = p;                                    // pointers into this level's (and the parent's) buffers, scalars of the step
     }
@@ -722,9 +717,6 @@ int ensure_rho(LudwigLevel *L)
     for (int part = 0; part < N_PARTS; ++part) {
         LudwigLevel::RhoReplay &rr = L->rho_replay[part];
         if (!rr.stale) continue;
-        if (rr.lost)
-            return fail(LUDWIG_ERR_STATE, "rho of part %d was left unwritten by step %lld and a later launch of another part has reused its inputs: "
-                        "read rho after a complete step, or set LUDWIG_EAGER_RHO=1", part, (long long)rr.t_sub);
         SCParams p = rr.p;
         p.store_rho = 1;
         for (int c = 1; c < N_CLASSES; ++c) {
@@ -1102,6 +1094,53 @@ int ludwig_level_set_stream(LudwigLevel *L, void *hip_stream)
 {
     if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
     L->stream = (hipStream_t)hip_stream;
+    return LUDWIG_OK;
+}
+
+int ludwig_stream_create(int device, int reserved_cus, void **stream_out)
+{
+    if (!stream_out) return fail(LUDWIG_ERR_INVALID, "null argument");
+    *stream_out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return fail(LUDWIG_ERR_NO_DEVICE, "no HIP device %d", device);
+    LW_HIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    if (reserved_cus <= 0) {
+        LW_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        *stream_out = st;
+        return LUDWIG_OK;
+    }
+    int n_cu = 0;
+    LW_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+    if (reserved_cus > n_cu / 2) return fail(LUDWIG_ERR_INVALID, "%d of %d compute units reserved: at most half", reserved_cus, n_cu);
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    for (int i = 0; i < n_cu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    // Which bit is which CU is not documented for multi-XCD parts: XCD-interleaved (bit i = XCD i mod 8) or XCD-contiguous
+    // (bit i = XCD i / 32). Bits 33 j + 8 m (j = 0..7) hit every residue mod 8 AND every group of 32 equally often, so
+    // the reserved CUs are spread over the XCDs under either numbering (256 CUs in 8 XCDs; other sizes: evenly spaced bits).
+    int done = 0;
+    if (n_cu == 256) {
+        for (int m = 0; done < reserved_cus && m < 4; ++m)
+            for (int j = 0; j < 8 && done < reserved_cus; ++j, ++done) {
+                const int bit = 33 * j + 8 * m;
+                mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+            }
+    }
+    for (int k = 0; done < reserved_cus; ++k) {      // generic / remainder: evenly spaced, skipping bits already cleared
+        const int bit = (int)(((int64_t)k * n_cu) / reserved_cus + 5) % n_cu;
+        if (mask[(size_t)bit / 32] & (1u << (bit % 32))) { mask[(size_t)bit / 32] &= ~(1u << (bit % 32)); ++done; }
+        if (k > 4 * n_cu) break;
+    }
+    LW_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()));
+    *stream_out = st;
+    return LUDWIG_OK;
+}
+
+int ludwig_stream_destroy(int device, void *hip_stream)
+{
+    if (!hip_stream) return LUDWIG_OK;
+    LW_HIP(hipSetDevice(device));
+    LW_HIP(hipStreamDestroy((hipStream_t)hip_stream));
     return LUDWIG_OK;
 }
 

@@ -28,6 +28,7 @@ Pure-numpy planning (build_local_level, compute_needs, interpolation_needs, Halo
 from __future__ import annotations
 
 from dataclasses import dataclass, field
+import os
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -281,6 +282,10 @@ class HaloExchanger:
         self.stage = stage_through_host
         self.device = torch.device(device)
         self.timing = False                # bench.py: bracket every exchange with events on the stream it runs on
+        # peer of the plan -> rank the message really travels to / from. Identity in production. The RCCL loop-back test
+        # (tests/_rccl_loopback_worker.py) plays rank 0 of a brick decomposition whose bricks hold identical data and maps every
+        # peer to rank 0 itself, so that the real transport runs on a box with one GPU.
+        self.wire_rank: Dict[int, int] = {}
         self._events = []
         self.idx_send, self.idx_recv, self.buf_send, self.buf_recv, self.seg_send, self.seg_recv = {}, {}, {}, {}, {}, {}
         for name in FIELD_GROUPS:
@@ -334,10 +339,11 @@ class HaloExchanger:
                     if d > c:
                         rcv[n][c:d].copy_(snd[n][a:b])
                     continue
+                w = self.wire_rank.get(p, p)
                 if b > a:
-                    ops.append(dist.P2POp(dist.isend, snd[n][a:b], p))
+                    ops.append(dist.P2POp(dist.isend, snd[n][a:b], w))
                 if d > c:
-                    ops.append(dist.P2POp(dist.irecv, rcv[n][c:d], p))
+                    ops.append(dist.P2POp(dist.irecv, rcv[n][c:d], w))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
@@ -356,6 +362,17 @@ class HaloExchanger:
         out = [a.elapsed_time(b) for a, b in self._events]
         self._events = []
         return out
+
+
+def init_rccl(local_rank: int) -> None:
+    """`torch.distributed` over RCCL with RCCL's kernels on a HIGH-priority stream. Not a tuning nicety: HIP serves the streams of one
+    priority from a small pool of hardware queues, and a send/recv kernel that lands in the queue of the compute stream starts only
+    when the stream-collide launch ahead of it has drained - the exchange is then not overlapped at all (seen in the loop-back
+    trace: profiles/r02_rccl_loopback_trace_same_queue.txt). Streams of another priority get queues of their own."""
+    import torch
+    import torch.distributed as dist
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), pg_options=opts)
 
 
 def exchange_requests(my_requests: Dict[int, Dict[str, np.ndarray]], world: int, rank: int) -> Dict[int, Dict[str, np.ndarray]]:
@@ -416,8 +433,18 @@ class DistributedLevelRunner:
         torch.cuda.set_device(device)
         self.level = adapt(view.level, device)
         self.dev = torch.device("cuda", device)
-        self.s_comp = torch.cuda.current_stream(self.dev)
-        self.s_comm = torch.cuda.Stream(self.dev) if overlap else self.s_comp
+        # overlap: the stepping stream leaves a few compute units to the exchange (include/ludwig_hip.h: ludwig_stream_create;
+        # LUDWIG_COMM_RESERVED_CUS, 0 = none), pack / unpack and RCCL run at high priority (init_rccl)
+        self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "16")) if overlap else 0
+        self._own_stream = None
+        if overlap and self.reserved_cus > 0:
+            ptr = C.c_void_p()
+            _lib.check(_lib.load().ludwig_stream_create(device, self.reserved_cus, C.byref(ptr)))
+            self._own_stream = ptr.value
+            self.s_comp = torch.cuda.ExternalStream(ptr.value, device=self.dev)
+        else:
+            self.s_comp = torch.cuda.current_stream(self.dev)
+        self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
         self.level.set_stream(self.s_comp.cuda_stream)
         if order is not None:
             coords = np.asarray(view.level.active_block_coords)
@@ -443,16 +470,22 @@ class DistributedLevelRunner:
         self.ex = HaloExchanger(plan, view.rank, self.dev, pack, unpack, stage_through_host)
         self.ev_boundary = torch.cuda.Event()
         self.ev_exchanged = torch.cuda.Event()
+        self.ev_post, self.ev_post_done = torch.cuda.Event(), torch.cuda.Event()
         self._have_exchange = False
+        self._noted = None                 # (f, vel) field names of the exchange the last step left to be enqueued
 
     def step(self, t: int, u_curr=0.0) -> None:
         """One step with the halo exchange hidden behind the NEXT step's interior blocks:
-             compute stream : interior(t) | wait exchange(t-1) | boundary(t) | [f_post halo, Bouzidi correction(t)]
-             comm stream    :  ... exchange(t-1) ...                                            | exchange(t) ...
+             host           : launch interior(t) | enqueue exchange(t-1) | launch boundary(t) ...
+             compute stream : interior(t)        | wait exchange(t-1)    | boundary(t) | [f_post halo, Bouzidi correction(t)]
+             comm stream    :                      exchange(t-1): pack, send/recv, unpack
         Interior blocks (no ghost neighbour) read and write owned cells only, so they may run while the ghosts of their input
-        are still arriving; the boundary blocks wait for them. Levels with Bouzidi cells follow the same schedule: the
-        correction rewrites f_out after the collision from the post-collision values of neighbour cells, so its small
-        f_post halo (only the links that reach across a cut) is exchanged in between, and the f / u halo goes last."""
+        are still arriving; the boundary blocks wait for them. The exchange of step t is only NOTED at the end of step t and
+        enqueued after the interior launch of step t + 1: putting a grouped send/recv together costs the host > 0.1 ms, and a
+        device that has not been handed the interior blocks yet idles through it (first seen in the RCCL loop-back trace,
+        profiles/r02_rccl_loopback_*). Levels with Bouzidi cells follow the same schedule: the correction rewrites f_out after the
+        collision from the post-collision values of neighbour cells, so its small f_post halo (only the links that reach across a
+        cut) is exchanged in between and waited for, and the f / u halo goes last."""
         from .physics import apply_bouzidi_correction, stream_collide
         _lib = self._lib
         torch = self.torch
@@ -466,27 +499,43 @@ class DistributedLevelRunner:
             self.ex.exchange(out_f, out_v)
             return
         stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_INTERIOR)
+        self.flush()                                        # exchange(t-1), with the device busy on the interior blocks
         if self._have_exchange:
             self.s_comp.wait_event(self.ev_exchanged)       # ghosts of this step's input are in place
         stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_BOUNDARY)
         if self.level.has_post_collision:
             if self.ex.plan.has("f_post"):
-                self.ev_boundary.record(self.s_comp)
+                self.ev_post.record(self.s_comp)
                 with torch.cuda.stream(self.s_comm):
-                    self.s_comm.wait_event(self.ev_boundary)
+                    self.s_comm.wait_event(self.ev_post)
                     self.ex.exchange_post_collision()
-                    self.ev_exchanged.record(self.s_comm)
-                self.s_comp.wait_event(self.ev_exchanged)
+                    self.ev_post_done.record(self.s_comm)
+                self.s_comp.wait_event(self.ev_post_done)
             apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
         self.ev_boundary.record(self.s_comp)
-        with torch.cuda.stream(self.s_comm):
+        self._noted = (out_f, out_v)
+
+    def flush(self) -> None:
+        """enqueue the exchange noted by the last step (no-op if there is none): after it the ghosts hold that step's output"""
+        if self._noted is None:
+            return
+        with self.torch.cuda.stream(self.s_comm):
             self.s_comm.wait_event(self.ev_boundary)
-            self.ex.exchange(out_f, out_v)
+            self.ex.exchange(*self._noted)
             self.ev_exchanged.record(self.s_comm)
+        self._noted = None
         self._have_exchange = True
 
     def synchronize(self) -> None:
+        self.flush()
         self.torch.cuda.synchronize(self.dev)
+
+    def close(self) -> None:
+        self.synchronize()
+        self.level.close()
+        if self._own_stream:
+            self._lib.check(self._lib.load().ludwig_stream_destroy(self.dev.index, self.C.c_void_p(self._own_stream)))
+            self._own_stream = None
 
 
 def distributed_level(global_level: BlockLevel, owner: np.ndarray, params, rank: int, world: int, device: int, overlap: bool = True,
@@ -712,7 +761,7 @@ class MultiLevelRunner:
         self.levels = [adapt(v.level, device) if v.level.n_blocks > 0 else None for v in self.views]
         self.overlap = overlap
         self.s_comp = torch.cuda.current_stream(self.dev)
-        self.s_comm = torch.cuda.Stream(self.dev) if overlap else self.s_comp
+        self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
         for L in self.levels:
             if L is not None:
                 L.set_stream(self.s_comp.cuda_stream)

@@ -1,4 +1,4 @@
-"""Stepping rate of a ball1m variant / the real wing (3 levels) without diagnostics. usage: case_speed.py re266k|re10m|wing [coarse steps]"""
+"""Stepping rate of a ball1m variant / the real wing (3 levels) without diagnostics. usage: case_speed.py re266k|re10m|wing [coarse steps] [nowall]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +13,9 @@ name = "wing5deg" if which == "wing" else "ball1m"
 cfg = pp.load_case_configuration(os.path.join(G, name + "_config.yaml"), ov)
 grids, mesh, params, rep = pp.setup_multilevel_domain(cfg, os.path.join(G, "wing5deg_model.stl" if which == "wing" else "ball1m.stl"))
 sp = pp.solver_params(cfg, params)
+if "nowall" in sys.argv[3:]:      # experiment: what the wall-model force costs (results differ, speed only)
+    import dataclasses
+    sp = dataclasses.replace(sp, wall_model_active=False)
 st = case.HipStepper(grids)
 for i, d in enumerate(st.dev):
     inf = d.info()
