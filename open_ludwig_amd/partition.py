@@ -55,7 +55,8 @@ class LocalView:
 
 
 def build_local_level(level_id: int, coords: Sequence[Tuple[int, int, int]], neighbor_table: np.ndarray, owner: np.ndarray,
-                      rank: int, tau: float, temporal: bool = False, extra_ghosts: Optional[np.ndarray] = None) -> LocalView:
+                      rank: int, tau: float, temporal: bool = False, extra_ghosts: Optional[np.ndarray] = None,
+                      widen_x_runs: bool = False) -> LocalView:
     """Cut rank `rank`'s local level out of the global block list (coords + global neighbor_table, 1-based).
     extra_ghosts: further remote blocks (global ids, 0-based) to keep a ghost copy of - parent data of this rank's finer
     blocks (required_parent_blocks)."""
@@ -78,6 +79,15 @@ def build_local_level(level_id: int, coords: Sequence[Tuple[int, int, int]], nei
     lvl.n_owned = len(owned)
     cb = np.zeros(len(l2g), dtype=np.uint8)
     cb[: len(owned)] = (table[: len(owned)] > len(owned)).any(axis=1)
+    if widen_x_runs and len(owned):
+        # A boundary block on an x face has its x neighbours in the interior part: alone in its launch it cannot join an x-run
+        # (the workgroup of 4 x-consecutive blocks that hands face columns over through LDS) and reads them as strided columns.
+        # Taking the whole aligned group of 4 into the boundary part keeps the runs whole; a superset of the blocks that must
+        # wait for the halo is always valid.
+        oc = coords[owned]
+        key = ((oc[:, 0] - 1) // 4) * (int(coords[:, 1].max()) + 1) * (int(coords[:, 2].max()) + 1) + oc[:, 1] * (int(coords[:, 2].max()) + 1) + oc[:, 2]
+        marked = np.unique(key[cb[: len(owned)] != 0])
+        cb[: len(owned)] = np.isin(key, marked)
     lvl.comm_boundary = cb
     return LocalView(rank, lvl, l2g, {int(g): i for i, g in enumerate(l2g)}, len(owned), owner[ghosts])
 
@@ -435,7 +445,7 @@ class DistributedLevelRunner:
         self.dev = torch.device("cuda", device)
         # overlap: the stepping stream leaves a few compute units to the exchange (include/ludwig_hip.h: ludwig_stream_create;
         # LUDWIG_COMM_RESERVED_CUS, 0 = none), pack / unpack and RCCL run at high priority (init_rccl)
-        self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "16")) if overlap else 0
+        self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "8")) if overlap else 0
         self._own_stream = None
         if overlap and self.reserved_cus > 0:
             ptr = C.c_void_p()
@@ -887,7 +897,7 @@ def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int
     grid = rank_grid(world)
     nbg = tuple(nb_per_rank[i] * grid[i] for i in range(3))
     coords, table, owner = periodic_box_topology(nbg, grid)
-    view = build_local_level(1, coords, table, owner, rank, tau)
+    view = build_local_level(1, coords, table, owner, rank, tau, widen_x_runs=os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0")
     cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), u0, share_ab_buffers=True)    # host level is only uploaded
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)
