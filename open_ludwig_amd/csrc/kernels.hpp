@@ -131,12 +131,16 @@ __device__ __forceinline__ float trilin(float v000, float v100, float v010, floa
 }
 
 // ---- wall-model force, reference src/physics_kernels.jl:206-236 ----
-__device__ __noinline__ void wall_model_force(float dist_wall, float tau_molecular, float rho, float ux, float uy, float uz,
-                                              float &Fx, float &Fy, float &Fz)
+#ifndef LW_WALL_INLINE
+#define LW_WALL_INLINE __noinline__
+#endif
+// Returns the magnitude of the force, or -1 where the reference leaves F = 0; the caller turns it into F = -mag u / |u|.
+// (One float in registers each way: with F returned through three references the call went through the stack - 16 B of
+// scratch per lane - and the kernel lost a wave per SIMD.)
+__device__ LW_WALL_INLINE float wall_model_force_mag(float dist_wall, float tau_molecular, float rho, float u_mag)
 {
-    Fx = 0.0f; Fy = 0.0f; Fz = 0.0f;
+    float force_mag = -1.0f;
     if (dist_wall > 0.0f && dist_wall < 10.0f) {
-        const float u_mag = sqrtf(ux * ux + uy * uy + uz * uz);
         const float nu_visc = (tau_molecular - 0.5f) / 3.0f;
         if (u_mag > 1.0e-6f && nu_visc > 1.0e-10f) {
             float u_tau = u_mag * jl_pow(nu_visc / (dist_wall * u_mag + 1.0e-10f), 1.0f / 7.0f) *
@@ -152,14 +156,10 @@ __device__ __noinline__ void wall_model_force(float dist_wall, float tau_molecul
             }
             const float tau_wall = rho * u_tau * u_tau;
             const float tau_res = rho * nu_visc * (u_mag / dist_wall);
-            if (tau_wall > tau_res) {
-                const float force_mag = (tau_wall - tau_res) / dist_wall;
-                Fx = -force_mag * ux / u_mag;
-                Fy = -force_mag * uy / u_mag;
-                Fz = -force_mag * uz / u_mag;
-            }
+            if (tau_wall > tau_res) force_mag = (tau_wall - tau_res) / dist_wall;
         }
     }
+    return force_mag;
 }
 
 // ---- addressing helpers -------------------------------------------------------------------------------------
@@ -370,7 +370,15 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     float Fx = 0.0f, Fy = 0.0f, Fz = 0.0f;
     float ux_eq = ux, uy_eq = uy, uz_eq = uz;          // u + 0.5 F / rho with F = 0
     if constexpr (WALL) {
-        if (flags & FLAG_HAS_NEAR_WALL) wall_model_force(ld_f32(p.wall_dist, own_bytes), p.tau, rho, ux, uy, uz, Fx, Fy, Fz);
+        if (flags & FLAG_HAS_NEAR_WALL) {
+            const float u_mag = sqrtf(ux * ux + uy * uy + uz * uz);
+            const float force_mag = wall_model_force_mag(ld_f32(p.wall_dist, own_bytes), p.tau, rho, u_mag);
+            if (force_mag >= 0.0f) {
+                Fx = -force_mag * ux / u_mag;
+                Fy = -force_mag * uy / u_mag;
+                Fz = -force_mag * uz / u_mag;
+            }
+        }
         ux_eq = ux + 0.5f * Fx * inv_rho;
         uy_eq = uy + 0.5f * Fy * inv_rho;
         uz_eq = uz + 0.5f * Fz * inv_rho;

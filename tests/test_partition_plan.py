@@ -199,3 +199,25 @@ def test_parent_ghosts_cover_every_interpolation_stencil(world):
                 assert np.array_equal(ga, gb), (rank, i, name, ga.size, gb.size)
             total += a["f"].size
     assert total > 0
+
+
+def test_widened_boundary_part_keeps_whole_x_runs():
+    """build_local_level(widen_x_runs=True): the boundary part is a superset of the blocks with a ghost neighbour, and along x it
+    consists of whole aligned groups of 4 blocks (the stream-collide kernel's workgroup), so no boundary block steps without its run."""
+    nb, grid = 8, (2, 2, 2)
+    nbg = tuple(nb * g for g in grid)
+    coords, table, owner = partition.periodic_box_topology(nbg, grid)
+    plain = partition.build_local_level(1, coords, table, owner, 0, 0.5006)
+    wide = partition.build_local_level(1, coords, table, owner, 0, 0.5006, widen_x_runs=True)
+    n = plain.n_owned
+    a, b = plain.level.comm_boundary[:n] != 0, wide.level.comm_boundary[:n] != 0
+    assert a.sum() == nb ** 3 - (nb - 2) ** 3 and (b | a).sum() == b.sum() and b.sum() > a.sum()
+    c = np.asarray(wide.level.active_block_coords)[:n]
+    groups = {}
+    for (bx, by, bz), m in zip(c, b):
+        groups.setdefault(((bx - 1) // 4, by, bz), []).append(bool(m))
+    assert all(len(v) == 4 and len(set(v)) == 1 for v in groups.values())
+    assert not wide.level.comm_boundary[n:].any()
+    # interior blocks still have no ghost neighbour
+    ghosty = (np.asarray(wide.level.neighbor_table)[:n] > n).any(axis=1)
+    assert not (ghosty & ~b).any()
