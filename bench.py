@@ -185,6 +185,10 @@ def main():
     per_launch = [a.elapsed_time(b) for a, b in ev]
     kern_ms = float(np.mean(per_launch))
     kern_med = float(np.median(per_launch))
+    if runner is not None:
+        # N > 1: a step is two launches (interior, boundary) with a wait for the halo in between: the per-step wall time of the
+        # timed region stands in for the kernel time (an upper bound).
+        kern_ms = kern_med = wall / args.steps * 1e3
 
     if dist is not None:
         red_dev = "cpu" if rehearsal else "cuda"

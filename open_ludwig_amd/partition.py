@@ -446,12 +446,14 @@ class DistributedLevelRunner:
         # overlap: the stepping stream leaves a few compute units to the exchange (include/ludwig_hip.h: ludwig_stream_create;
         # LUDWIG_COMM_RESERVED_CUS, 0 = none), pack / unpack and RCCL run at high priority (init_rccl)
         self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "8")) if overlap else 0
-        self._own_stream = None
+        self._own_streams = []
         if overlap and self.reserved_cus > 0:
-            ptr = C.c_void_p()
-            _lib.check(_lib.load().ludwig_stream_create(device, self.reserved_cus, C.byref(ptr)))
-            self._own_stream = ptr.value
-            self.s_comp = torch.cuda.ExternalStream(ptr.value, device=self.dev)
+            def masked_stream():
+                ptr = C.c_void_p()
+                _lib.check(_lib.load().ludwig_stream_create(device, self.reserved_cus, C.byref(ptr)))
+                self._own_streams.append(ptr.value)
+                return torch.cuda.ExternalStream(ptr.value, device=self.dev)
+            self.s_comp = masked_stream()
         else:
             self.s_comp = torch.cuda.current_stream(self.dev)
         self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
@@ -495,7 +497,9 @@ class DistributedLevelRunner:
         device that has not been handed the interior blocks yet idles through it (first seen in the RCCL loop-back trace,
         profiles/r02_rccl_loopback_*). Levels with Bouzidi cells follow the same schedule: the correction rewrites f_out after the
         collision from the post-collision values of neighbour cells, so its small f_post halo (only the links that reach across a
-        cut) is exchanged in between and waited for, and the f / u halo goes last."""
+        cut) is exchanged in between and waited for, and the f / u halo goes last.
+        (Stepping the two parts on two streams - boundary(t) only needs step t - 1 and the ghosts - was measured and gives nothing:
+        0.752 vs 0.744 ms, profiles/r02_split_penalty_no_exchange.txt.)"""
         from .physics import apply_bouzidi_correction, stream_collide
         _lib = self._lib
         torch = self.torch
@@ -543,9 +547,9 @@ class DistributedLevelRunner:
     def close(self) -> None:
         self.synchronize()
         self.level.close()
-        if self._own_stream:
-            self._lib.check(self._lib.load().ludwig_stream_destroy(self.dev.index, self.C.c_void_p(self._own_stream)))
-            self._own_stream = None
+        for ptr in self._own_streams:
+            self._lib.check(self._lib.load().ludwig_stream_destroy(self.dev.index, self.C.c_void_p(ptr)))
+        self._own_streams = []
 
 
 def distributed_level(global_level: BlockLevel, owner: np.ndarray, params, rank: int, world: int, device: int, overlap: bool = True,

@@ -26,9 +26,30 @@ for name, mask in (("shell", shell), ("shell widened to aligned groups of 4 in x
             for p in parts: stream_collide(d, None, np.float32(0.5), np.float32(0.0), params, t, part=p)
             t += 1
         torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+    s2 = torch.cuda.Stream()
+    ev_i, ev_b = [torch.cuda.Event(), torch.cuda.Event()], torch.cuda.Event()
+    def run_two_streams(n=100):
+        """interior on one stream, boundary on another: each waits for the other part of the PREVIOUS step only"""
+        t = 1
+        def step(t, k):
+            if k: st.wait_event(ev_b)
+            d.set_stream(st.cuda_stream); stream_collide(d, None, np.float32(0.5), np.float32(0.0), params, t, part=_lib.PART_INTERIOR)
+            ev_i[k % 2].record(st)
+            if k: s2.wait_event(ev_i[(k - 1) % 2])
+            d.set_stream(s2.cuda_stream); stream_collide(d, None, np.float32(0.5), np.float32(0.0), params, t, part=_lib.PART_BOUNDARY)
+            ev_b.record(s2)
+            d.set_stream(st.cuda_stream)
+        k = 0
+        for _ in range(20):
+            step(t, k); t += 1; k += 1
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n):
+            step(t, k); t += 1; k += 1
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
     print(f"{name}: boundary part {int(mask.sum())} of {len(mask)} blocks", flush=True)
     for rep in range(2):
         a = run((_lib.PART_ALL,)); b = run((_lib.PART_INTERIOR, _lib.PART_BOUNDARY))
         bo = run((_lib.PART_BOUNDARY,)); io = run((_lib.PART_INTERIOR,))     # one part over and over: timing only
-        print(f"  one launch {a:.4f} ms | interior + boundary {b:.4f} ms | alone: interior {io:.4f}, boundary {bo:.4f}", flush=True)
+        two = run_two_streams()
+        print(f"  one launch {a:.4f} ms | interior + boundary {b:.4f} ms, on two streams {two:.4f} ms | alone: interior {io:.4f}, boundary {bo:.4f}", flush=True)
     d.close()
