@@ -11,8 +11,16 @@ grids, params = cases.periodic_box((nb, nb, nb), upload_only=True)
 g = grids[0]
 c = np.asarray(g.active_block_coords)
 shell = ((c == 1) | (c == nb)).any(axis=1)
-for name, mask in (("shell", shell), ("shell widened to aligned groups of 4 in x", shell | np.isin((c[:, 0] - 1) // 4, (0, (nb - 1) // 4)))):
-    g.comm_boundary = mask.astype(np.uint8)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _rccl_loopback_worker as lw
+view, plan, vparams = lw.symmetric_brick_plan((2, 2, 2), nb)      # rank 0's brick of a 2x2x2 decomposition: the same blocks + ghost copies
+configs = [("shell", shell, g, params), ("shell widened to aligned groups of 4 in x", shell | np.isin((c[:, 0] - 1) // 4, (0, (nb - 1) // 4)), g, params),
+           ("brick view: owned blocks + ghost blocks behind them (widened)", None, view.level, vparams)]
+for name, mask, g, params in configs:
+    if mask is None:
+        mask = g.comm_boundary[: view.n_owned] != 0
+    else:
+        g.comm_boundary = mask.astype(np.uint8)
     d = adapt(g, 0)
     st = torch.cuda.current_stream()
     d.set_stream(st.cuda_stream)
