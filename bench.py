@@ -266,7 +266,8 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_LUP * cells_per_rank,
                          "traffic_unit": "fabric-side bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",
                          "traffic_source": traffic_source, "source_digest": digest,
-                         "rho_store": "elided (reproduced on demand, DESIGN 3.1)" if not os.environ.get("LUDWIG_EAGER_RHO") else "eager"},
+                         "rho_store": ("stored (boundary / interior part launches always store it)" if runner is not None else
+                                       "elided (reproduced on demand, DESIGN 3.1)" if not os.environ.get("LUDWIG_EAGER_RHO") else "eager")},
         }
         if comm is not None:
             out["comm"] = comm
