@@ -111,6 +111,9 @@ struct LudwigLevel {
         float tw = 0.0f, tau_parent = 0.0f;
         int use_temporal = 0;
     } ahead[N_PARTS];
+    // Interface values produced BEFORE the step that uses them (interface_prepass: level streams run a parent level's interface
+    // pass ahead of its wait for the children, see recursive_step): same keys as IfaceAhead, values in f_iface.
+    IfaceAhead prepared[N_PARTS];
     // Lazy rho. The step writes `rho` (4 of 244 B per cell update) for readers that mostly are not there: the next step
     // overwrites it unread unless a child level interpolates from it (every step), or a diagnostic / download / save asks
     // for it (now and then). A level nobody has read `rho` of in between therefore skips the store and remembers the
@@ -131,6 +134,9 @@ struct LudwigLevel {
     hipEvent_t ev_stepped = nullptr;    // recorded on this level's stream after each of its steps (collision + Bouzidi)
     hipEvent_t ev_consumed = nullptr;   // recorded on the CHILD's stream once its interface pass has read this level's buffers
     bool ev_consumed_set = false;
+    uint64_t stepped_gen = 0;           // how often ev_stepped has been recorded
+    const LudwigLevel *waited_parent = nullptr;   // the parent step this level's stream has already been made to wait for
+    uint64_t waited_gen = 0;
     uint64_t version = 0;               // bumped by everything that writes this level's fields
     const LudwigLevel *iface_parent = nullptr;
     std::vector<int32_t> h_block_pointer;   // [gdx,gdy,gdz] 1-based, 0 = absent (src/blocks.jl:111-114)
@@ -543,6 +549,102 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
     return LUDWIG_OK;
 }
 
+// the parent-side pointers of a step / an interface pass for sub-step t_sub
+static void fill_parent_params(SCParams &p, const LudwigLevel *parent, int64_t t_sub)
+{
+    if (parent) {
+        const int pout = ((t_sub >> 1) % 2 == 0) ? 1 : 0;   // output buffer of the parent's step t_sub >> 1
+        p.pf_new = parent->f[pout];
+        p.pvel_new = parent->vel[pout];
+        p.prho_new = parent->rho;
+        // without temporal storage the reference passes 1-element dummies that are never read
+        // (use_temporal_interp is then false at every call site that matters); alias "new" to stay in bounds
+        p.pf_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->f[parent->old_alias] : parent->f_old) : parent->f[pout];
+        p.prho_old = parent->has_temporal ? parent->rho_old : parent->rho;
+        p.pvel_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->vel[parent->old_alias] : parent->vel_old) : parent->vel[pout];
+        p.psk = parent->sk;
+        p.is_level_1 = 0;
+    } else {
+        p.is_level_1 = 1;
+    }
+}
+
+// Coarse -> fine interface pass for the general blocks of `part` (reference src/physics_kernels.jl:122-137): leaves p.f_iface
+// pointing at the values sub-step t_sub loads. ahead_of_step: called by interface_prepass, before the step's own launch.
+static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, SCParams &p, int64_t t_sub, float parent_tau,
+                          float temporal_weight, bool ahead_of_step)
+{
+    if (!parent || L->n_items[part][1] == 0) return LUDWIG_OK;
+    const int r = build_interface_links(L, parent, p.nx_g, p.ny_g, p.nz_g);
+    if (r) return r;
+    p.f_iface = L->f_iface;
+    p.n_iface_blocks = L->n_iface_blocks;
+    if (L->n_links[part] == 0) return LUDWIG_OK;
+    LudwigLevel::IfaceAhead &pre = L->prepared[part];
+    const bool ready = pre.valid && pre.parent == parent && pre.parent_version == parent->version && pre.t_sub == t_sub &&
+                       pre.tw == temporal_weight && pre.tau_parent == parent_tau && pre.use_temporal == p.use_temporal;
+    pre.valid = ready && ahead_of_step;
+    if (ready) return LUDWIG_OK;                 // produced by interface_prepass; the look-ahead record for t_sub + 1 stays as it is
+    LudwigLevel::IfaceAhead &ah = L->ahead[part];
+    const bool hit = ah.valid && ah.parent == parent && ah.parent_version == parent->version && ah.t_sub == t_sub &&
+                     ah.tw == temporal_weight && ah.tau_parent == parent_tau && ah.use_temporal == p.use_temporal;
+    if (hit && ahead_of_step) return LUDWIG_OK;  // nothing to do ahead: the step will find the values in f_iface2
+    ah.valid = false;
+    if (hit) {
+        p.f_iface = L->f_iface2;                 // computed together with the previous sub-step's values
+        return LUDWIG_OK;
+    }
+    // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
+    const bool two = (t_sub % 2 == 0) && !parent->external_writer && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
+    InterfaceArgs a{};
+    a.corners = L->sources[part]; a.weights = L->source_w[part];
+    a.mac = L->source_mac[part]; a.mac2 = L->source_mac2[part];
+    a.links = L->links[part];
+    a.f_iface2 = L->f_iface2;
+    a.tw2 = 0.5f;
+    a.n_sources = L->n_sources[part]; a.n_links = L->n_links[part];
+    const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
+    if (two) {
+        hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, L->stream, p, a);
+        hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, L->stream, p, a);
+        ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
+        ah.tw = a.tw2; ah.tau_parent = parent_tau; ah.use_temporal = p.use_temporal;
+    } else {
+        hipLaunchKernelGGL(k_interface_sources<false>, gs, dim3(256), 0, L->stream, p, a);
+        hipLaunchKernelGGL(k_interface_links<false>, gl, dim3(256), 0, L->stream, p, a);
+    }
+    LW_HIP(hipGetLastError());
+    if (ahead_of_step) {
+        pre.valid = true; pre.parent = parent; pre.parent_version = parent->version; pre.t_sub = t_sub;
+        pre.tw = temporal_weight; pre.tau_parent = parent_tau; pre.use_temporal = p.use_temporal;
+    }
+    // level streams (ludwig_execute_timestep_batch): the parent's buffers have been read - the last time for this
+    // pair of sub-steps when the values for the second one were produced alongside
+    if (parent->ev_consumed && L->own_stream && L->stream == L->own_stream) {
+        LW_HIP(hipEventRecord(parent->ev_consumed, L->stream));
+        const_cast<LudwigLevel *>(parent)->ev_consumed_set = true;
+    }
+    return LUDWIG_OK;
+}
+
+// The interface pass of sub-step t_sub, launched before the step itself. It reads the PARENT's buffers and writes this level's
+// interface side buffers only, so a level with children can run it before it waits for them (recursive_step).
+static int interface_prepass(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float parent_tau, float temporal_weight,
+                             const LudwigStepFlags *fl)
+{
+    if (!parent || L->n_blocks == 0 || L->n_items[LUDWIG_PART_ALL][1] == 0) return LUDWIG_OK;
+    LW_HIP(hipSetDevice(L->device));
+    SCParams p{};
+    fill_parent_params(p, parent, t_sub);
+    p.tau = L->tau;
+    p.tau_parent = parent_tau;
+    p.temporal_weight = temporal_weight;
+    const int scale = 1 << (L->level_id - 1);
+    p.nx_g = fl->domain_nx * scale; p.ny_g = fl->domain_ny * scale; p.nz_g = fl->domain_nz * scale;
+    p.use_temporal = (fl->use_temporal_interp && parent->has_temporal) ? 1 : 0;
+    return interface_pass(L, parent, LUDWIG_PART_ALL, p, t_sub, parent_tau, temporal_weight, true);
+}
+
 int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float u_curr, float parent_tau,
                           float temporal_weight, const LudwigStepFlags *fl, int part)
 {
@@ -572,21 +674,7 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     p.wall_dist = L->wall_dist;
     p.meta = L->meta;
     p.sk = L->sk;
-    if (parent) {
-        const int pout = ((t_sub >> 1) % 2 == 0) ? 1 : 0;   // output buffer of the parent's step t_sub >> 1
-        p.pf_new = parent->f[pout];
-        p.pvel_new = parent->vel[pout];
-        p.prho_new = parent->rho;
-        // without temporal storage the reference passes 1-element dummies that are never read
-        // (use_temporal_interp is then false at every call site that matters); alias "new" to stay in bounds
-        p.pf_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->f[parent->old_alias] : parent->f_old) : parent->f[pout];
-        p.prho_old = parent->has_temporal ? parent->rho_old : parent->rho;
-        p.pvel_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->vel[parent->old_alias] : parent->vel_old) : parent->vel[pout];
-        p.psk = parent->sk;
-        p.is_level_1 = 0;
-    } else {
-        p.is_level_1 = 1;
-    }
+    fill_parent_params(p, parent, t_sub);
     p.tau = L->tau;
     p.tau_parent = parent_tau;
     p.c_wale = fl->c_wale;
@@ -626,48 +714,9 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     }
 
     const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
-    if (parent && L->n_items[part][1] > 0) {
-        // coarse -> fine interface pass for the general blocks of this part (reference src/physics_kernels.jl:122-137)
-        const int r = build_interface_links(L, parent, p.nx_g, p.ny_g, p.nz_g);
+    {
+        const int r = interface_pass(L, parent, part, p, t_sub, parent_tau, temporal_weight, false);
         if (r) return r;
-        p.f_iface = L->f_iface;
-        p.n_iface_blocks = L->n_iface_blocks;
-        if (L->n_links[part] > 0) {
-            LudwigLevel::IfaceAhead &ah = L->ahead[part];
-            const bool hit = ah.valid && ah.parent == parent && ah.parent_version == parent->version && ah.t_sub == t_sub &&
-                             ah.tw == temporal_weight && ah.tau_parent == parent_tau && ah.use_temporal == p.use_temporal;
-            ah.valid = false;
-            if (hit) {
-                p.f_iface = L->f_iface2;          // computed together with the previous sub-step's values
-            } else {
-                // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
-                const bool two = (t_sub % 2 == 0) && !parent->external_writer && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
-                InterfaceArgs a{};
-                a.corners = L->sources[part]; a.weights = L->source_w[part];
-                a.mac = L->source_mac[part]; a.mac2 = L->source_mac2[part];
-                a.links = L->links[part];
-                a.f_iface2 = L->f_iface2;
-                a.tw2 = 0.5f;
-                a.n_sources = L->n_sources[part]; a.n_links = L->n_links[part];
-                const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
-                if (two) {
-                    hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, L->stream, p, a);
-                    hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, L->stream, p, a);
-                    ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
-                    ah.tw = a.tw2; ah.tau_parent = parent_tau; ah.use_temporal = p.use_temporal;
-                } else {
-                    hipLaunchKernelGGL(k_interface_sources<false>, gs, dim3(256), 0, L->stream, p, a);
-                    hipLaunchKernelGGL(k_interface_links<false>, gl, dim3(256), 0, L->stream, p, a);
-                }
-                LW_HIP(hipGetLastError());
-                // level streams (ludwig_execute_timestep_batch): the parent's buffers have been read - the last time for this
-                // pair of sub-steps when the values for the second one were produced alongside
-                if (parent->ev_consumed && L->own_stream && L->stream == L->own_stream) {
-                    LW_HIP(hipEventRecord(parent->ev_consumed, L->stream));
-                    const_cast<LudwigLevel *>(parent)->ev_consumed_set = true;
-                }
-            }
-        }
     }
     for (int c = 0; c < N_CLASSES; ++c) {
         if (L->n_items[part][c] == 0) continue;
@@ -1340,13 +1389,32 @@ static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-
     const bool has_children = lvl < n_levels;
     int rc;
     if (concurrent) {
-        if (has_children && L->ev_consumed_set) LW_HIP(hipStreamWaitEvent(L->stream, L->ev_consumed, 0));
-        if (parent) LW_HIP(hipStreamWaitEvent(L->stream, parent->ev_stepped, 0));
+        // every event operation costs the stream ~7 us between two kernels (kernel trace of the 3-level sphere): wait for a
+        // parent step once, not once per sub-step
+        if (parent && (L->waited_parent != parent || L->waited_gen != parent->stepped_gen)) {
+            LW_HIP(hipStreamWaitEvent(L->stream, parent->ev_stepped, 0));
+            L->waited_parent = parent; L->waited_gen = parent->stepped_gen;
+        }
+        if (has_children && L->ev_consumed_set) {
+            // This level's own interface pass reads the parent and writes side buffers: it need not wait for the children to have
+            // read THIS level's buffers, only the step behind it must. Running it ahead shortens what is left to do after the wait.
+            // That pays when this level is not much smaller than its child - its step then comes in late for the child's next
+            // pair of sub-steps (3-level sphere, 1000 blocks under 1728: 25 us late per coarse step, 0.370 -> 0.337 ms) - and costs
+            // when the child dwarfs it and nothing was late (wing, 1728 under 5256: 0.848 -> 0.883 ms of added contention).
+            // LUDWIG_IFACE_HOIST=0 / 1 overrides the size rule.
+            static const char *he = getenv("LUDWIG_IFACE_HOIST");
+            const bool hoist = he ? atoi(he) != 0 : 20 * (int64_t)L->n_blocks >= 9 * (int64_t)levels[lvl]->n_blocks;
+            if (hoist && (rc = interface_prepass(L, parent, t_sub, parent_tau, temporal_weight, fl))) return rc;
+            LW_HIP(hipStreamWaitEvent(L->stream, L->ev_consumed, 0));
+        }
     }
     if (has_children && fl->use_temporal_interp && L->has_temporal)
         if ((rc = ludwig_save_old(L, t_sub))) return rc;
     if ((rc = ludwig_step(L, parent, t_sub, u_vel, parent_tau, temporal_weight, fl))) return rc;
-    if (concurrent && has_children) LW_HIP(hipEventRecord(L->ev_stepped, L->stream));
+    if (concurrent && has_children) {
+        LW_HIP(hipEventRecord(L->ev_stepped, L->stream));
+        ++L->stepped_gen;
+    }
     if (has_children) {
         if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub, L, L->tau, 0.0f, u_vel, fl, concurrent))) return rc;
         if ((rc = recursive_step(levels, n_levels, lvl + 1, 2 * t_sub + 1, L, L->tau, 0.5f, u_vel, fl, concurrent))) return rc;
@@ -1383,6 +1451,7 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
                 LW_HIP(hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming));
             }
             L->ev_consumed_set = false;
+            L->waited_parent = nullptr;
             L->stream = L->own_stream;
             if (i + 1 < n_levels && !L->rho_eager) {            // children interpolate from rho after every step
                 L->rho_eager = true;

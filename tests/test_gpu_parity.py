@@ -433,3 +433,30 @@ def test_reference_behaviour_switches_give_the_same_bits(gpu, tmp_path):
         for n in (fn, vn, "rho"):
             assert np.array_equal(d.download(n), getattr(g, n)), (i, n)
         d.close()
+
+
+@pytest.mark.parametrize("hoist", ["0", "1"])
+def test_interface_pass_ahead_of_the_wait_gives_the_same_bits(gpu, tmp_path, hoist):
+    """Level streams: a level with a parent AND children may run its own interface pass before it waits for its children to have
+    read its buffers (recursive_step, LUDWIG_IFACE_HOIST; by default a size rule decides). Forced on and forced off, in fresh
+    processes, over two batches: the fields of all three levels equal the oracle's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np, sys; sys.path.insert(0, %r)\n"
+            "from open_ludwig_amd import adapt, cases, execute_timestep_batch\n"
+            "g, p = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)\n"
+            "d = [adapt(x, 0) for x in g]\n"
+            "execute_timestep_batch(d, 1, 3, np.float32(0.05), p)\n"
+            "execute_timestep_batch(d, 4, 4, np.float32(0.05), p)\n"
+            "np.savez(sys.argv[1], **{f'{n}{i}': x.download(n) for i, x in enumerate(d) for n in ('f', 'f_temp', 'vel', 'vel_temp', 'rho')})\n" % root)
+    out = str(tmp_path / "hoist.npz")
+    subprocess.run([sys.executable, "-c", code.replace("\\n", "\n"), out], check=True, env=dict(os.environ, LUDWIG_IFACE_HOIST=hoist))
+    got = np.load(out)
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)
+    oracle.execute_timestep_batch(grids, 1, 7, np.float32(0.05), params)
+    for i, g in enumerate(grids):
+        fn, vn = oracle.newest_buffers(i, 7)
+        for n in (fn, vn, "rho"):
+            assert np.array_equal(got[f"{n}{i}"], getattr(g, n)), (i, n)
