@@ -460,3 +460,31 @@ def test_interface_pass_ahead_of_the_wait_gives_the_same_bits(gpu, tmp_path, hoi
         fn, vn = oracle.newest_buffers(i, 7)
         for n in (fn, vn, "rho"):
             assert np.array_equal(got[f"{n}{i}"], getattr(g, n)), (i, n)
+
+
+def test_stepping_stream_with_reserved_compute_units(gpu):
+    """ludwig_stream_create: a stream whose kernels leave some compute units alone (for the halo exchange of the multi-GPU
+    schedule). Stepping on it gives the bits of the default stream; more than half the device reserved is refused."""
+    import ctypes as C
+    from open_ludwig_amd import _lib
+    lib = _lib.load()
+    grids, params = cases.periodic_box((4, 3, 2))
+    cases.init_perturbed(grids[0], 11)
+    d = adapt(grids[0], 0)
+    st = C.c_void_p()
+    _lib.check(lib.ludwig_stream_create(0, 8, C.byref(st)))
+    assert st.value
+    d.set_stream(st.value)
+    execute_timestep_batch([d], 1, 4, np.float32(0.0), params)
+    oracle.execute_timestep_batch(grids, 1, 4, np.float32(0.0), params)
+    fn, vn = oracle.newest_buffers(0, 4)
+    for n in (fn, vn, "rho"):
+        assert np.array_equal(d.download(n), getattr(grids[0], n)), n
+    d.set_stream(None)
+    d.close()
+    _lib.check(lib.ludwig_stream_destroy(0, st))
+    bad = C.c_void_p()
+    assert lib.ludwig_stream_create(0, 100000, C.byref(bad)) == -1 and bad.value is None
+    plain = C.c_void_p()
+    _lib.check(lib.ludwig_stream_create(0, 0, C.byref(plain)))            # 0 reserved: an ordinary stream
+    _lib.check(lib.ludwig_stream_destroy(0, plain))

@@ -62,6 +62,10 @@ def test_error_reporting_without_device():
         with pytest.raises(_lib.LudwigError) as e:
             adapt(grids[0], 0)
         assert e.value.code == -3                                         # LUDWIG_ERR_NO_DEVICE
+        st = C.c_void_p(1)
+        assert lib.ludwig_stream_create(0, 8, C.byref(st)) == -3 and st.value is None     # no device: no stream, no fallback
+    assert lib.ludwig_stream_create(0, 8, None) == -1
+    assert lib.ludwig_stream_destroy(0, None) == 0                        # destroying "no stream" is a no-op
 
 
 def test_product_package_never_imports_the_oracle():
