@@ -414,6 +414,29 @@ def rank_grid(world: int) -> Tuple[int, int, int]:
     return tuple(g)
 
 
+def stride_padding_blocks(n_local: int, owner: np.ndarray, rank: int, present: np.ndarray) -> np.ndarray:
+    """Extra remote blocks (global ids) to keep as never-read ghost copies, only to move the level's block count - i.e. the distance
+    between two populations in device memory, n_blocks x 2 KiB - off the values at which the stepping kernel loses 5-17 % on MI355X
+    (27 + 27 streams that far apart hit the memory channels unevenly; `profiles/r02_population_stride_sweep.txt`: 68, 76-77, 83, 86
+    and 90 MiB are bad, 65-75 and 84 MiB good; a 2-rank brick of 256^3 cells lands on 68.0 MiB, an 8-rank brick on 76.8).
+    LUDWIG_VIEW_PAD_BLOCKS=n overrides the table (0 = no padding)."""
+    env = os.environ.get("LUDWIG_VIEW_PAD_BLOCKS")
+    if env is not None:
+        pad = int(env)
+    else:
+        mib = n_local / 512.0
+        bad = ((67.5, 68.5, 69.0), (75.5, 83.5, 84.0), (85.5, 86.5, 87.0), (89.5, 90.5, 91.0))     # (from, to, go to) in MiB
+        pad = 0
+        for lo, hi, to in bad:
+            if lo <= mib <= hi:
+                pad = int(round(to * 512)) - n_local
+    if pad <= 0:
+        return np.zeros(0, np.int64)
+    cand = np.flatnonzero(owner != rank)
+    cand = cand[~np.isin(cand, present)]
+    return cand[:pad]
+
+
 def periodic_box_topology(nb_global: Tuple[int, int, int], grid: Tuple[int, int, int]):
     """coords (reference order), periodic neighbor_table and the brick owner of every block."""
     nbx, nby, nbz = nb_global
@@ -901,7 +924,11 @@ def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int
     grid = rank_grid(world)
     nbg = tuple(nb_per_rank[i] * grid[i] for i in range(3))
     coords, table, owner = periodic_box_topology(nbg, grid)
-    view = build_local_level(1, coords, table, owner, rank, tau, widen_x_runs=os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0")
+    widen = os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0"
+    view = build_local_level(1, coords, table, owner, rank, tau, widen_x_runs=widen)
+    extra = stride_padding_blocks(view.level.n_blocks, owner, rank, view.local_to_global)
+    if len(extra):
+        view = build_local_level(1, coords, table, owner, rank, tau, widen_x_runs=widen, extra_ghosts=extra)
     cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), u0, share_ab_buffers=True)    # host level is only uploaded
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)

@@ -221,3 +221,20 @@ def test_widened_boundary_part_keeps_whole_x_runs():
     # interior blocks still have no ghost neighbour
     ghosty = (np.asarray(wide.level.neighbor_table)[:n] > n).any(axis=1)
     assert not (ghosty & ~b).any()
+
+
+def test_stride_padding_moves_a_view_off_the_bad_block_counts(monkeypatch):
+    """partition.stride_padding_blocks: remote blocks kept as never-read ghost copies so that n_blocks x 2 KiB - the distance between
+    two populations - leaves the values measured as bad on MI355X (68 MiB: a 2-rank brick of 256^3 cells). Small views, views at
+    good strides and an explicit 0 get nothing; the extra blocks are remote and not present yet."""
+    monkeypatch.delenv("LUDWIG_VIEW_PAD_BLOCKS", raising=False)
+    owner = np.array([0] * 34000 + [1] * 6000)
+    present = np.arange(34816)                       # 34 000 owned + 816 ghosts of rank 1 = 68.0 MiB
+    extra = partition.stride_padding_blocks(34816, owner, 0, present)
+    assert len(extra) == 69 * 512 - 34816 and (owner[extra] == 1).all() and not np.isin(extra, present).any()
+    assert len(partition.stride_padding_blocks(36992, owner, 0, present)) == 0          # 72.25 MiB: fine as it is
+    assert len(partition.stride_padding_blocks(1000, owner, 0, present)) == 0
+    monkeypatch.setenv("LUDWIG_VIEW_PAD_BLOCKS", "0")
+    assert len(partition.stride_padding_blocks(34816, owner, 0, present)) == 0
+    monkeypatch.setenv("LUDWIG_VIEW_PAD_BLOCKS", "7")
+    assert len(partition.stride_padding_blocks(1000, owner, 0, present)) == 7
