@@ -53,16 +53,19 @@ def test_symmetric_brick_plan_reproduces_the_one_brick_box_cpu(grid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,nb,steps", [("2x1x1", 4, 7), ("2x2x2", 4, 8)])
-def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps):
+@pytest.mark.parametrize("grid,nb,steps,pad", [("2x1x1", 4, 7, None), ("2x2x2", 4, 8, None), ("2x2x2", 4, 6, "37")])
+def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps, pad):
     """The production exchange (pack -> grouped isend/irecv on RCCL -> unpack on the comm stream, interior blocks stepping under
-    it) with all 1 / 7 peers wired to rank 0: fields identical to the single-device run of the one-brick box."""
+    it) with all 1 / 7 peers wired to rank 0: fields identical to the single-device run of the one-brick box. pad: the view carries
+    extra never-read ghost blocks (partition.stride_padding_blocks, what the bench path does at 256^3 per brick)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if pad is not None:
+        env["LUDWIG_VIEW_PAD_BLOCKS"] = pad
     out = tmp_path / "rep.json"
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_loopback_worker.py"), grid, str(nb), str(steps), str(out)],
                          capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
@@ -71,3 +74,5 @@ def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps):
     assert rep["backend"] == "nccl" and rep["collectives_ok"]
     assert rep["peers"] == {"2x1x1": 1, "2x2x2": 7}[grid]
     assert rep["moved"] and all(rep["identical"].values()), rep
+    if pad is not None:
+        assert rep["view_blocks"] == 4 ** 3 + (6 ** 3 - 4 ** 3) + int(pad)
