@@ -89,6 +89,11 @@ def cpu_baseline(size: int, seconds: float):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON: libraries that chat on stdout (gloo's "connected to n peer ranks", RCCL's banner) are sent
+    # to stderr at the file-descriptor level for the whole run; the JSON line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch   # first: its bundled HIP runtime is the one the whole process shares (same SONAME as /opt/rocm's)
     from open_ludwig_amd import _lib, adapt, cases, order as order_mod
@@ -273,7 +278,8 @@ def main():
             out["comm"] = comm
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
