@@ -16,6 +16,9 @@ Before the W warm-up steps the device is kept busy for --preheat-ms (default 60 
 scratch buffers - no stepping - because the step time shows a 25-step power-management transient after any idle period and the set-up
 leaves the device idle; `config.device_preheat_ms` reports it, `--preheat-ms 0` turns it off.
 
+Kernel time: HIP events on the launch stream around the timed region, divided by K (one launch per step at N = 1); every
+--event-every-th step (default 10) is bracketed on its own as well, for the spread. stdout carries the JSON line only.
+
 `roofline.traffic` comes from rocprofv3 PMC passes, which cannot run inside this process: it is read from
 profiles/traffic.json and reported ONLY if that file was captured with the very sources the loaded library was built from
 (`source_digest`) on the same workload size; otherwise it is null and `traffic_source` says why. Capture: tools/final_profile.sh.
@@ -45,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-size", type=int, default=64)
     ap.add_argument("--no-overlap", action="store_true", help="multi-GPU: exchange halos after the whole step")
+    ap.add_argument("--event-every", type=int, default=10,
+                    help="bracket every N-th step with its own pair of HIP events (an event between two launches costs the stream a few "
+                         "microseconds); the timed region as a whole is always bracketed")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="keep the device busy with plain memory copies (no stepping) for this long right before the warm-up steps, so that "
                          "the W + K steps run at settled clocks (0 = off)")
@@ -178,18 +184,30 @@ def main():
     if runner is not None:
         runner.ex.exchange_ms()          # drop the warm-up exchanges
         runner.ex.timing = True
-    # timed region: EXACTLY --steps steps; per-launch kernel time from events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # timed region: EXACTLY --steps steps
+    # kernel time: HIP events on the launch stream around the WHOLE timed region (average launch duration = span / K; with one launch per
+    # step and nothing else on the stream the span is the launches plus ~1 us between them) and, for the spread, around every
+    # --event-every-th step on its own. Not around every step: an event record between two launches costs the stream 5-7 us.
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev = []
+    every = max(1, args.event_every)
     t0 = time.perf_counter()
+    region[0].record(stream)
     for i in range(args.steps):
-        ev[i][0].record(stream)
+        sampled = i % every == every // 2
+        if sampled:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
         step(t); t += 1
-        ev[i][1].record(stream)
+        if sampled:
+            b.record(stream)
+            ev.append((a, b))
+    region[1].record(stream)
     barrier()
     wall = time.perf_counter() - t0
     per_launch = [a.elapsed_time(b) for a, b in ev]
-    kern_ms = float(np.mean(per_launch))
-    kern_med = float(np.median(per_launch))
+    kern_ms = region[0].elapsed_time(region[1]) / args.steps
+    kern_med = float(np.median(per_launch)) if per_launch else kern_ms
     if runner is not None:
         # N > 1: a step is two launches (interior, boundary) with a wait for the halo in between: the per-step wall time of the
         # timed region stands in for the kernel time (an upper bound).
@@ -267,7 +285,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kernel, "kernel_ms": round(kern_ms, 4), "kernel_ms_median": round(kern_med, 4),
-                         "kernel_ms_first5_last5": [round(float(np.mean(per_launch[:5])), 4), round(float(np.mean(per_launch[-5:])), 4)],
+                         "kernel_ms_sampled_first_last": [round(per_launch[0], 4), round(per_launch[-1], 4)] if per_launch else None,
+                         "kernel_ms_source": ("HIP events on the launch stream around the timed region / steps; median of individually "
+                                              f"bracketed steps (every {every}th)") if runner is None else "wall clock per step (N > 1)",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_LUP * cells_per_rank,
                          "traffic_unit": "fabric-side bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",
                          "traffic_source": traffic_source, "source_digest": digest,
