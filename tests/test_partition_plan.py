@@ -39,7 +39,7 @@ def _run_partitioned(nbg, world, steps, grid=None):
     return views, plans, (coords, table, params)
 
 
-@pytest.mark.parametrize("nbg,world", [((4, 2, 2), 2), ((4, 4, 2), 4), ((4, 4, 4), 8), ((2, 2, 2), 8), ((6, 2, 3), 2)])
+@pytest.mark.parametrize("nbg,world", [((4, 2, 2), 2), ((4, 4, 2), 4), ((4, 4, 4), 8), ((2, 2, 2), 8), ((3, 2, 6), 2)])
 def test_partitioned_oracle_matches_single_domain(nbg, world):
     steps = 4
     views, plans, (coords, table, params) = _run_partitioned(nbg, world, steps)
