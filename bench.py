@@ -5,8 +5,9 @@ A "step" = one pass of the hot path (pull-stream + regularised-BGK/WALE collide;
 over every cell of a synthetic uniform periodic box, inputs resident in HBM when the timed region starts.
 
   N = 1 : BASELINE configs[1] - 256^3 periodic box, D3Q27 reg-BGK + WALE, FP32 (SURVEY.md section 8d "C2").
-  N > 1 : weak scaling - every rank owns a 256^3 brick of one global periodic box (8 ranks = configs[3], 512^3),
-          one-cell halo of f and u exchanged every step over RCCL (torch.distributed backend "nccl").
+  N > 1 : weak scaling - every rank owns 256^3 cells of one global periodic box (2, 4 ranks: cubic bricks cut in z, then y; 8 ranks =
+          configs[3], the 512^3 box, cut 1 x 2 x 4 into bricks of 512 x 256 x 128 cells: partition.weak_scaling_layout), one-cell
+          halo of f and u exchanged every step over RCCL (torch.distributed backend "nccl").
 
 Prints ONE JSON line (rank 0). `roofline` prices the stream-collide kernel against the 8 TB/s HBM peak with the
 algorithmic 216 B per lattice update; `cpu_baseline` is the CPU oracle (a port, NOT the reference's Julia CPU
@@ -144,13 +145,14 @@ def main():
             stream_collide(level, None, np.float32(0.5), np.float32(0.0), params, t)
     else:
         from open_ludwig_amd import partition
-        runner = partition.periodic_weak_scaling_box(rank, world, (nb, nb, nb), device=local_rank,
+        brick, rgrid = partition.weak_scaling_layout(world, nb)
+        runner = partition.periodic_weak_scaling_box(rank, world, brick, device=local_rank,
                                                       overlap=not args.no_overlap, order=args.order,
-                                                      stage_through_host=rehearsal)
+                                                      stage_through_host=rehearsal, grid=rgrid)
         level = runner.level
         stream = runner.s_comp               # the stepping stream (leaves LUDWIG_COMM_RESERVED_CUS compute units to the exchange)
         if rank == 0:
-            print(f"[bench] backend {dist.get_backend()} reports world size {dist.get_world_size()}; rank grid {partition.rank_grid(world)}; "
+            print(f"[bench] backend {dist.get_backend()} reports world size {dist.get_world_size()}; rank grid {rgrid}, {brick} blocks per rank; "
                   f"halo {runner.ex.plan.bytes_per_step() / 1e6:.2f} MB per rank per step", file=sys.stderr, flush=True)
 
         def step(t):
@@ -230,7 +232,7 @@ def main():
         x = torch.tensor([float(np.mean(ms)) if ms else 0.0, float(np.max(ms)) if ms else 0.0], dtype=torch.float64,
                          device="cpu" if rehearsal else "cuda")
         dist.all_reduce(x, op=dist.ReduceOp.MAX)
-        comm = {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(), "rank_grid": list(partition.rank_grid(world)),
+        comm = {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(), "rank_grid": list(rgrid), "blocks_per_rank": list(brick),
                 "halo_bytes_per_rank_per_step": runner.ex.plan.bytes_per_step(), "peers_of_rank0": len([p for p in runner.ex.plan.peers if p != rank]),
                 "exchange_ms_mean_max_over_ranks": round(float(x[0].item()), 4), "exchange_ms_worst": round(float(x[1].item()), 4),
                 "overlap": not args.no_overlap, "compute_units_left_to_the_exchange": runner.reserved_cus,
@@ -274,8 +276,9 @@ def main():
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.size}^3 uniform periodic box per GPU, D3Q27 regularized-BGK + WALE, "
-                                   f"Taylor-Green start (SURVEY 8d C2)" + ("" if world == 1 else f"; {world} bricks, one-cell halo of f,u per step over RCCL"),
+            "config": {"workload": f"uniform periodic box, {args.size}^3 cells per GPU, D3Q27 regularized-BGK + WALE, "
+                                   f"Taylor-Green start (SURVEY 8d C2)" + ("" if world == 1 else f"; {world} bricks of {brick[0] * 8}x{brick[1] * 8}x{brick[2] * 8} cells in a "
+                                                                     f"{rgrid[0]}x{rgrid[1]}x{rgrid[2]} rank grid, one-cell halo of f,u per step over RCCL"),
                        "cells_per_gpu": cells_per_rank, "global_cells": total_cells, "tau": 0.5006, "c_wale": 0.5,
                        "nu_sgs_background": 0.0005, "launch_order": args.order or "library default",
                        "device_preheat_ms": args.preheat_ms,

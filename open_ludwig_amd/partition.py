@@ -918,13 +918,26 @@ class MultiLevelRunner:
         self.torch.cuda.synchronize(self.dev)
 
 
+def weak_scaling_layout(world: int, nb: int) -> Tuple[Tuple[int, int, int], Tuple[int, int, int]]:
+    """(blocks per rank along x, y, z; ranks along x, y, z) of bench.py's weak-scaling box: nb^3 blocks per rank whatever the
+    world size. 2 and 4 ranks: cubic bricks, z and y cut (rank_grid). 8 ranks: the 2 nb-cube (BASELINE configs[3], 512^3 cells at
+    nb = 32) cut 1 x 2 x 4 into bricks of 2 nb x nb x nb/2 blocks rather than 2 x 2 x 2 cubes - no x face at all (rank_grid's
+    docstring; loop-back, same box: 0.875 against 0.920 ms per step) and at most 6.3 MB per peer and step; slabs (1 x 1 x 8) measure
+    the same but put 12.6 MB on each of two links."""
+    if world == 8 and nb % 2 == 0:
+        return (2 * nb, nb, nb // 2), (1, 2, 4)
+    return (nb, nb, nb), rank_grid(world)
+
+
 def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int, int], device: int, overlap: bool = True,
-                              order: Optional[str] = None, stage_through_host: bool = False, tau: float = 0.5006, u0: float = 0.03):
-    """bench.py N > 1 workload: every rank owns an nb_per_rank brick of one periodic Taylor-Green box (BASELINE
-    configs[3] at 8 ranks x 32^3 blocks = 512^3 cells)."""
+                              order: Optional[str] = None, stage_through_host: bool = False, tau: float = 0.5006, u0: float = 0.03,
+                              grid: Optional[Tuple[int, int, int]] = None):
+    """bench.py N > 1 workload: every rank owns an nb_per_rank brick of one periodic Taylor-Green box cut into `grid` ranks
+    (default rank_grid(world); bench.py: weak_scaling_layout - 8 ranks x 32^3 blocks = BASELINE configs[3], 512^3 cells)."""
     from . import cases
     from .physics import SolverParams
-    grid = rank_grid(world)
+    grid = tuple(grid) if grid is not None else rank_grid(world)
+    assert grid[0] * grid[1] * grid[2] == world
     nbg = tuple(nb_per_rank[i] * grid[i] for i in range(3))
     coords, table, owner = periodic_box_topology(nbg, grid)
     widen = os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0"

@@ -31,14 +31,15 @@ def symmetric_brick_plan(grid, nb, upload_only=True):
     one brick, and a halo plan whose send lists are what the PEERS would send - read from the same places of rank 0's own brick."""
     from open_ludwig_amd import cases, partition
     from open_ludwig_amd.physics import SolverParams
-    nbg = tuple(nb * g for g in grid)
+    nb3 = (nb, nb, nb) if isinstance(nb, int) else tuple(nb)          # blocks per brick edge, or per axis
+    nbg = tuple(nb3[i] * grid[i] for i in range(3))
     coords, table, owner = partition.periodic_box_topology(nbg, grid)
     widen = os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0"
     view = partition.build_local_level(1, coords, table, owner, 0, 0.5006, widen_x_runs=widen)
     extra = partition.stride_padding_blocks(view.level.n_blocks, owner, 0, view.local_to_global)      # as the bench path does
     if len(extra):
         view = partition.build_local_level(1, coords, table, owner, 0, 0.5006, widen_x_runs=widen, extra_ghosts=extra)
-    cases.init_taylor_green(view.level, (8 * nb, 8 * nb, 8 * nb), 0.03, share_ab_buffers=upload_only)      # period = one brick
+    cases.init_taylor_green(view.level, tuple(8 * n for n in nb3), 0.03, share_ab_buffers=upload_only)      # period = one brick
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)
     n_global = len(coords)
@@ -46,7 +47,7 @@ def symmetric_brick_plan(grid, nb, upload_only=True):
 
     def in_my_brick(goff: np.ndarray, p: int) -> np.ndarray:
         """global element offsets inside brick p -> the same places of brick 0 (owner = (ix * g1 + iy) * g2 + iz)"""
-        shift = (p // (grid[1] * grid[2]) * nb, (p // grid[2]) % grid[1] * nb, p % grid[2] * nb)
+        shift = (p // (grid[1] * grid[2]) * nb3[0], (p // grid[2]) % grid[1] * nb3[1], p % grid[2] * nb3[2])
         comp, rem = np.divmod(goff, n_global * 512)
         gblk, cell = np.divmod(rem, 512)
         bx, r2 = np.divmod(gblk, nbg[1] * nbg[2])
@@ -61,7 +62,8 @@ def symmetric_brick_plan(grid, nb, upload_only=True):
 
 def main():
     grid = tuple(int(v) for v in sys.argv[1].split("x"))
-    nb, steps, out_path = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    nb = int(sys.argv[2]) if "," not in sys.argv[2] else tuple(int(v) for v in sys.argv[2].split(","))
+    steps, out_path = int(sys.argv[3]), sys.argv[4]
     compare = len(sys.argv) < 6 or sys.argv[5] != "nocompare"
     torch.cuda.set_device(0)
     from open_ludwig_amd import partition as _p
@@ -144,7 +146,7 @@ def main():
         fn, vn = ("f_temp", "vel_temp") if steps % 2 == 0 else ("f", "vel")
         got = {n: runner.level.download(n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
         own_coords = [tuple(c) for c in np.asarray(view.level.active_block_coords)[: view.n_owned]]
-        grids, params1 = cases.periodic_box((nb, nb, nb), upload_only=True)
+        grids, params1 = cases.periodic_box((nb, nb, nb) if isinstance(nb, int) else nb, upload_only=True)
         pos = {tuple(c): i for i, c in enumerate(grids[0].active_block_coords)}
         sel = np.array([pos[c] for c in own_coords])
         single = adapt(grids[0], 0)

@@ -39,10 +39,11 @@ def _run_partitioned(nbg, world, steps, grid=None):
     return views, plans, (coords, table, params)
 
 
-@pytest.mark.parametrize("nbg,world", [((4, 2, 2), 2), ((4, 4, 2), 4), ((4, 4, 4), 8), ((2, 2, 2), 8), ((3, 2, 6), 2)])
-def test_partitioned_oracle_matches_single_domain(nbg, world):
+@pytest.mark.parametrize("nbg,world,grid", [((4, 2, 2), 2, None), ((4, 4, 2), 4, None), ((4, 4, 4), 8, None), ((2, 2, 2), 8, None),
+                                            ((3, 2, 6), 2, None), ((4, 4, 4), 8, (1, 2, 4)), ((2, 2, 8), 8, (1, 1, 8))])
+def test_partitioned_oracle_matches_single_domain(nbg, world, grid):
     steps = 4
-    views, plans, (coords, table, params) = _run_partitioned(nbg, world, steps)
+    views, plans, (coords, table, params) = _run_partitioned(nbg, world, steps, grid)
     grids, params1 = cases.periodic_box(nbg)
     oracle.execute_timestep_batch(grids, 1, steps, np.float32(0.0), params1)
     g = grids[0]
@@ -238,3 +239,14 @@ def test_stride_padding_moves_a_view_off_the_bad_block_counts(monkeypatch):
     assert len(partition.stride_padding_blocks(34816, owner, 0, present)) == 0
     monkeypatch.setenv("LUDWIG_VIEW_PAD_BLOCKS", "7")
     assert len(partition.stride_padding_blocks(1000, owner, 0, present)) == 7
+
+
+def test_weak_scaling_layout_keeps_the_cells_per_rank_and_the_global_box():
+    """bench.py's N > 1 boxes: nb^3 blocks per rank for every world size; 8 ranks = the (2 nb)^3 box (BASELINE configs[3]) cut
+    1 x 2 x 4 - no x face; 2 and 4 ranks cut z, then y."""
+    for world in (1, 2, 4, 8, 16):
+        brick, grid = partition.weak_scaling_layout(world, 32)
+        assert brick[0] * brick[1] * brick[2] == 32 ** 3 and grid[0] * grid[1] * grid[2] == world
+    assert partition.weak_scaling_layout(8, 32) == ((64, 32, 16), (1, 2, 4))
+    assert tuple(b * g for b, g in zip(*partition.weak_scaling_layout(8, 32))) == (64, 64, 64)
+    assert partition.weak_scaling_layout(2, 32) == ((32, 32, 32), (1, 1, 2)) and partition.weak_scaling_layout(4, 32)[1] == (1, 2, 2)

@@ -53,7 +53,7 @@ def test_symmetric_brick_plan_reproduces_the_one_brick_box_cpu(grid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,nb,steps,pad", [("2x1x1", 4, 7, None), ("2x2x2", 4, 8, None), ("2x2x2", 4, 6, "37")])
+@pytest.mark.parametrize("grid,nb,steps,pad", [("2x1x1", 4, 7, None), ("2x2x2", 4, 8, None), ("2x2x2", 4, 6, "37"), ("1x2x2", "8,4,2", 6, None)])
 def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps, pad):
     """The production exchange (pack -> grouped isend/irecv on RCCL -> unpack on the comm stream, interior blocks stepping under
     it) with all 1 / 7 peers wired to rank 0: fields identical to the single-device run of the one-brick box. pad: the view carries
@@ -72,7 +72,7 @@ def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps, pad):
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     rep = json.load(open(out))
     assert rep["backend"] == "nccl" and rep["collectives_ok"]
-    assert rep["peers"] == {"2x1x1": 1, "2x2x2": 7}[grid]
+    assert rep["peers"] == {"2x1x1": 1, "2x2x2": 7, "1x2x2": 3}[grid]      # 1x2x2 with 8 x 4 x 2 blocks: the shape of bench.py's 8-rank bricks
     assert rep["moved"] and all(rep["identical"].values()), rep
     if pad is not None:
         assert rep["view_blocks"] == 4 ** 3 + (6 ** 3 - 4 ** 3) + int(pad)

@@ -5,7 +5,7 @@ i=0
 for g in ${LOOP_GRIDS:-2x1x1 2x2x1 2x2x2}; do for pad in ${LOOP_PADS:-default 0 default 0}; do
   i=$((i+1)); export MASTER_PORT=$((29720+i))
   if [ "$pad" = default ]; then unset LUDWIG_VIEW_PAD_BLOCKS; else export LUDWIG_VIEW_PAD_BLOCKS=$pad; fi
-  timeout -k 10 300 python tests/_rccl_loopback_worker.py $g 32 240 gpurun_out/r2t/loop_${g}_pad${pad}_$i.json nocompare >/dev/null 2>&1 || exit 1
+  timeout -k 10 300 python tests/_rccl_loopback_worker.py $g ${LOOP_NB:-32} 240 gpurun_out/r2t/loop_${g}_pad${pad}_$i.json nocompare >/dev/null 2>&1 || exit 1
 done; done
 unset LUDWIG_VIEW_PAD_BLOCKS
 python bench.py --steps 200 --warmup 40 --cpu-seconds 0 2>/dev/null > gpurun_out/r2t/single2.json
