@@ -420,15 +420,17 @@ def rank_grid(world: int) -> Tuple[int, int, int]:
 def stride_padding_blocks(n_local: int, owner: np.ndarray, rank: int, present: np.ndarray) -> np.ndarray:
     """Extra remote blocks (global ids) to keep as never-read ghost copies, only to move the level's block count - i.e. the distance
     between two populations in device memory, n_blocks x 2 KiB - off the values at which the stepping kernel loses 5-17 % on MI355X
-    (27 + 27 streams that far apart hit the memory channels unevenly; `profiles/r02_population_stride_sweep.txt`: 68, 76-77, 83, 86
-    and 90 MiB are bad, 65-75 and 84 MiB good; a 2-rank brick of 256^3 cells lands on 68.0 MiB, an 8-rank brick on 76.8).
+    (27 + 27 streams that far apart hit the memory channels unevenly; `profiles/r02_population_stride_sweep.txt`: 68 MiB costs the
+    plain box 10-17 %, and a 2-rank brick of 256^3 cells lands exactly there: loop-back 0.93 -> 0.87 ms per step when moved to 69).
+    Only that value is in the table: the other spikes of the sweep (76-77, 83, 86, 90 MiB) gave nothing consistent when the 8-rank
+    views (76.5-76.8 MiB) were moved off them (`r02_rccl_loopback_8_rank_padding_targets.txt`).
     LUDWIG_VIEW_PAD_BLOCKS=n overrides the table (0 = no padding)."""
     env = os.environ.get("LUDWIG_VIEW_PAD_BLOCKS")
     if env is not None:
         pad = int(env)
     else:
         mib = n_local / 512.0
-        bad = ((67.5, 68.5, 69.0), (75.5, 83.5, 84.0), (85.5, 86.5, 87.0), (89.5, 90.5, 91.0))     # (from, to, go to) in MiB
+        bad = ((67.5, 68.5, 69.0),)     # (from, to, go to) in MiB
         pad = 0
         for lo, hi, to in bad:
             if lo <= mib <= hi:
