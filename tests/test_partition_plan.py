@@ -250,3 +250,25 @@ def test_weak_scaling_layout_keeps_the_cells_per_rank_and_the_global_box():
     assert partition.weak_scaling_layout(8, 32) == ((64, 32, 16), (1, 2, 4))
     assert tuple(b * g for b, g in zip(*partition.weak_scaling_layout(8, 32))) == (64, 64, 64)
     assert partition.weak_scaling_layout(2, 32) == ((32, 32, 32), (1, 1, 2)) and partition.weak_scaling_layout(4, 32)[1] == (1, 2, 2)
+
+
+def test_eight_rank_layout_has_three_equal_face_peers_and_no_x_face():
+    """weak_scaling_layout(8, nb): bricks of 2nb x nb x nb/2 blocks in a 1 x 2 x 4 rank grid - two z neighbours with one face each and
+    one y neighbour with both faces, the same bytes each (6.3 MB at nb = 32), two edge peers with a sliver, nothing across x."""
+    nb = 8
+    brick, grid = partition.weak_scaling_layout(8, nb)
+    nbg = tuple(brick[i] * grid[i] for i in range(3))
+    coords, table, owner = partition.periodic_box_topology(nbg, grid)
+    assert (np.bincount(owner) == nb ** 3).all()
+    view = partition.build_local_level(1, coords, table, owner, 5, 0.5006, widen_x_runs=True)
+    mine = partition.make_requests(view, len(coords))
+    per_peer = {p: 4 * sum(a.size for a in r.values()) for p, r in mine.items()}
+    assert len(per_peer) == 5
+    big = sorted(per_peer.values())[-3:]
+    face = brick[0] * brick[1] * 64 * (9 + 3) * 4              # one z face: 9 populations + 3 velocity components per cell
+    assert all(0.98 * face <= b <= face for b in big) and sum(sorted(per_peer.values())[:2]) < 0.02 * face      # rim cells go to the edge peers
+    gx = np.asarray(view.level.active_block_coords)[view.n_owned:, 0]
+    assert gx.min() >= 1 and gx.max() <= nbg[0] and view.level.n_blocks - view.n_owned == 2 * brick[0] * brick[1] + 2 * brick[0] * brick[2] + 4 * brick[0]
+    # the boundary part is whole x rows: widening to groups of 4 adds nothing
+    plain = partition.build_local_level(1, coords, table, owner, 5, 0.5006)
+    assert np.array_equal(plain.level.comm_boundary, view.level.comm_boundary)
