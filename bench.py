@@ -5,9 +5,19 @@ A "step" = one pass of the hot path (pull-stream + regularised-BGK/WALE collide;
 over every cell of a synthetic uniform periodic box, inputs resident in HBM when the timed region starts.
 
   N = 1 : BASELINE configs[1] - 256^3 periodic box, D3Q27 reg-BGK + WALE, FP32 (SURVEY.md section 8d "C2").
-  N > 1 : weak scaling - every rank owns 256^3 cells of one global periodic box (2, 4 ranks: cubic bricks cut in z, then y; 8 ranks =
-          configs[3], the 512^3 box, cut 1 x 2 x 4 into bricks of 512 x 256 x 128 cells: partition.weak_scaling_layout), one-cell
-          halo of f and u exchanged every step over RCCL (torch.distributed backend "nccl").
+  N > 1 : --scaling weak (default): every rank owns 256^3 cells of one global periodic box (2, 4 ranks: cubic bricks cut in z,
+          then y; 8 ranks = configs[3], the 512^3 box, cut 1 x 2 x 4 into bricks of 512 x 256 x 128 cells:
+          partition.weak_scaling_layout);
+          --scaling strong [--size 512]: the SAME global box at every N - configs[3] as BASELINE states it, "512^3 ... 1/2/4/8-GPU
+          scaling" - cut 1x1x2, 1x2x2, 1x2x4 (partition.strong_scaling_layout; N = 1 steps the whole box on one GPU).
+          One-cell halo of f and u exchanged every step over RCCL (torch.distributed backend "nccl").
+
+`python3 bench.py --gpus N` starts its own N ranks: when WORLD_SIZE is not in the environment and N > 1, a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` runs this file with the same arguments
+(a child process started before anything touches the GPU - never an exec), rank 0's JSON line and the child's exit code are relayed.
+Launched under torch.distributed.run by somebody else (WORLD_SIZE set), it is a rank. LUDWIG_BENCH_FORCE_DEVICE=0 rehearses N ranks on
+ONE GPU over gloo with host-staged messages (RCCL refuses two ranks on a device); --plan-only stops after the rendezvous and the halo
+plan (no GPU needed) and prints the `comm` object with "value": null.
 
 Prints ONE JSON line (rank 0). `roofline` prices the stream-collide kernel against the 8 TB/s HBM peak with the
 algorithmic 216 B per lattice update; `cpu_baseline` is the CPU oracle (a port, NOT the reference's Julia CPU
@@ -44,7 +54,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--size", type=int, default=256, help="cells per side of the per-GPU brick")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --size^3 cells per GPU whatever N; strong: one global box of --size^3 cells cut over the N GPUs")
+    ap.add_argument("--size", type=int, default=None,
+                    help="cells per side: of the per-GPU brick (weak, default 256) or of the global box (strong, default 512)")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="N > 1: rendezvous + halo plan only, on the CPU over gloo; prints the comm object with value null (no measurement)")
+    ap.add_argument("--eager-rho-steps", type=int, default=20,
+                    help="N = 1: after the timed region, time this many steps with rho stored by every step as the reference's kernel does "
+                         "(roofline.frac_eager_rho); 0 = skip")
     ap.add_argument("--order", default=None, help="launch-order builder (open_ludwig_amd/order.py); default = library default")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-size", type=int, default=64)
@@ -55,7 +73,35 @@ def parse():
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="keep the device busy with plain memory copies (no stepping) for this long right before the warm-up steps, so that "
                          "the W + K steps run at settled clocks (0 = off)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.size is None:
+        a.size = 512 if a.scaling == "strong" else 256
+    return a
+
+
+def launch_ranks(n: int) -> int:
+    """`python3 bench.py --gpus N` from a plain shell: run the N ranks as a CHILD torch.distributed.run (this process has not touched
+    the GPU and never does), relay rank 0's JSON line - the only thing that reaches stdout - and the child's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for l in res.stdout.splitlines():
+        if l.startswith("{") and '"metric"' in l:
+            line = l
+        elif l.strip():
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return res.returncode if res.returncode else (0 if line is not None else 1)
 
 
 def host_cores() -> int:
@@ -94,8 +140,59 @@ def cpu_baseline(size: int, seconds: float):
             "sample": f"{size}^3 periodic box, same parameters, {steps} steps in {dt:.1f} s (CPU oracle, OpenMP)"}
 
 
+def workload_text(args, world, brick, rgrid, box) -> str:
+    base = "uniform periodic box, D3Q27 regularized-BGK + WALE, Taylor-Green start (SURVEY 8d C2)"
+    if world == 1:
+        return f"{base}; {box[0]}^3 cells on one GPU" + (" (strong-scaling base: BASELINE configs[3] on one GPU)" if args.scaling == "strong" else "")
+    cut = (f"{world} bricks of {brick[0] * 8}x{brick[1] * 8}x{brick[2] * 8} cells in a {rgrid[0]}x{rgrid[1]}x{rgrid[2]} rank grid, "
+           "one-cell halo of f,u per step over RCCL")
+    if args.scaling == "strong":
+        return f"{base}; STRONG scaling: fixed global box of {box[0]}x{box[1]}x{box[2]} cells (BASELINE configs[3] at --size 512), {cut}"
+    return f"{base}; WEAK scaling: {args.size}^3 cells per GPU, global box {box[0]}x{box[1]}x{box[2]} cells, {cut}"
+
+
+def plan_only(args, world, rank, brick, rgrid, json_fd) -> None:
+    """--plan-only: the N ranks meet over gloo on the CPU, build and exchange the halo plan of the workload, and rank 0 prints the
+    comm object. No GPU, no stepping, no number: "value" is null."""
+    import numpy as np
+    import torch.distributed as dist
+    from open_ludwig_amd import partition
+    if world < 2:
+        raise SystemExit("--plan-only is for --gpus N > 1")
+    dist.init_process_group("gloo")
+    view, plan, _, n_global = partition.periodic_box_plan(rank, world, brick, rgrid, init=False)
+    peers = [p for p in plan.peers if p != rank]
+    per_peer = {int(p): 4 * sum(a.size for a in plan.send[p].values()) for p in peers}
+    stats = [None] * world
+    dist.all_gather_object(stats, {"halo_bytes": plan.bytes_per_step(), "peers": len(peers), "owned": int(view.n_owned), "blocks": int(view.level.n_blocks)})
+    if rank == 0:
+        box = tuple(8 * brick[i] * rgrid[i] for i in range(3))
+        out = {"metric": f"MLUPS (million lattice updates/s) at {args.size}^3 D3Q27; % of HBM roofline", "value": None, "unit": "MLUPS",
+               "n_gpus": world, "plan_only": True, "scaling": args.scaling,
+               "config": {"workload": workload_text(args, world, brick, rgrid, box), "scaling_mode": args.scaling, "global_box_cells": list(box),
+                          "cells_per_gpu": 512 * brick[0] * brick[1] * brick[2], "global_blocks": int(n_global)},
+               "comm": {"backend": dist.get_backend(), "backend_world_size": dist.get_world_size(), "rank_grid": list(rgrid), "blocks_per_rank": list(brick),
+                        "halo_bytes_per_rank_per_step": [s["halo_bytes"] for s in stats], "peers_per_rank": [s["peers"] for s in stats],
+                        "owned_blocks_per_rank": [s["owned"] for s in stats], "view_blocks_per_rank": [s["blocks"] for s in stats],
+                        "bytes_to_each_peer_of_rank0": per_peer}}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def kernel_label(info) -> str:
+    """the stepping kernel exactly as rocprofv3 --kernel-trace --stats prints it (profiles/*_kernel_stats.csv can be joined on it)"""
+    nw = 8 if os.environ.get("LUDWIG_XRUN") == "8" else 4
+    if os.environ.get("LUDWIG_NO_XRUN"):
+        return "void lw::k_stream_collide<false, false, false>(lw::SCParams)"
+    general = "true" if info.n_general_blocks > 0 and info.n_fast_blocks == 0 else "false"
+    return f"void lw::k_stream_collide_xrun<{nw}, {general}, false, false, false>(lw::SCParams)"
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     # stdout carries ONE line, the JSON: libraries that chat on stdout (gloo's "connected to n peer ranks", RCCL's banner) are sent
     # to stderr at the file-descriptor level for the whole run; the JSON line goes to the saved descriptor
     sys.stdout.flush()
@@ -113,10 +210,24 @@ def main():
     if rehearsal:
         local_rank = int(os.environ["LUDWIG_BENCH_FORCE_DEVICE"])
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.size % 8:
+        raise SystemExit("--size must be a multiple of the block size 8")
+    nb = args.size // 8
+    if world > 1:
+        from open_ludwig_amd import partition
+        brick, rgrid = (partition.strong_scaling_layout(world, nb) if args.scaling == "strong" else partition.weak_scaling_layout(world, nb))
+    else:
+        brick, rgrid = (nb, nb, nb), (1, 1, 1)
+    cells_per_rank = 512 * brick[0] * brick[1] * brick[2]
+    box = tuple(8 * brick[i] * rgrid[i] for i in range(3))
+    if args.plan_only:
+        return plan_only(args, world, rank, brick, rgrid, json_fd)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: --gpus {world} needs {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(LUDWIG_BENCH_FORCE_DEVICE=0 rehearses all ranks on one GPU over gloo)")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -124,11 +235,7 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")       # RCCL refuses two ranks on one device
         else:
-            from open_ludwig_amd import partition as _p
-            _p.init_rccl(local_rank)
-
-    nb = args.size // 8
-    cells_per_rank = (nb * 8) ** 3
+            partition.init_rccl(local_rank)
     stream = torch.cuda.current_stream()
 
     if world == 1:
@@ -144,8 +251,6 @@ def main():
         def step(t):
             stream_collide(level, None, np.float32(0.5), np.float32(0.0), params, t)
     else:
-        from open_ludwig_amd import partition
-        brick, rgrid = partition.weak_scaling_layout(world, nb)
         runner = partition.periodic_weak_scaling_box(rank, world, brick, device=local_rank,
                                                       overlap=not args.no_overlap, order=args.order,
                                                       stage_through_host=rehearsal, grid=rgrid)
@@ -221,9 +326,25 @@ def main():
         dist.all_reduce(w, op=dist.ReduceOp.MAX)      # slowest rank defines the step time
         wall, kern_ms = float(w[0].item()), float(w[1].item())
 
+    # N = 1, after the timed region: the same kernel with rho stored by every step, as the reference's kernel does
+    # (src/physics_kernels.jl:243-246) - the driver-observed price of the elided store
+    eager_ms = None
+    if runner is None and args.eager_rho_steps > 0 and not os.environ.get("LUDWIG_EAGER_RHO"):
+        level.set_rho_store(True)
+        for _ in range(5):
+            step(t); t += 1
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(args.eager_rho_steps):
+            step(t); t += 1
+        e1.record(stream)
+        torch.cuda.synchronize()
+        eager_ms = e0.elapsed_time(e1) / args.eager_rho_steps
+
     # sanity: the state must still be finite and the flow non-trivial (no skipped work)
     rho = level.download("rho")
     ok = bool(np.isfinite(rho).all() and rho.std() > 0)
+    del rho
 
     # multi-GPU: what the exchange cost, measured with events on the stream it ran on (diagnosis of the driver's scaling runs)
     comm = None
@@ -265,20 +386,14 @@ def main():
                                       f"with sources {digest}); not measured inside this process")
             except Exception as e:
                 traffic_source = f"profiles/traffic.json unreadable: {e}"
-        info = level.info()
-        nw = 8 if os.environ.get("LUDWIG_XRUN") == "8" else 4
-        general = info.n_general_blocks > 0
-        kernel = (f"lw::k_stream_collide_xrun<{nw},{'true' if general and info.n_fast_blocks == 0 else 'false'},false,false> (NW, GENERAL, POST, WALL)"
-                  + ("" if not general or info.n_fast_blocks == 0 else " + the GENERAL instantiation for blocks with a missing neighbour")
-                  + (" [LUDWIG_NO_XRUN: k_stream_collide]" if os.environ.get("LUDWIG_NO_XRUN") else ""))
+        kernel = kernel_label(level.info())
         out = {
             "metric": f"MLUPS (million lattice updates/s) at {args.size}^3 D3Q27; % of HBM roofline",
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"uniform periodic box, {args.size}^3 cells per GPU, D3Q27 regularized-BGK + WALE, "
-                                   f"Taylor-Green start (SURVEY 8d C2)" + ("" if world == 1 else f"; {world} bricks of {brick[0] * 8}x{brick[1] * 8}x{brick[2] * 8} cells in a "
-                                                                     f"{rgrid[0]}x{rgrid[1]}x{rgrid[2]} rank grid, one-cell halo of f,u per step over RCCL"),
+            "config": {"workload": workload_text(args, world, brick, rgrid, box),
+                       "scaling_mode": args.scaling, "global_box_cells": list(box),
                        "cells_per_gpu": cells_per_rank, "global_cells": total_cells, "tau": 0.5006, "c_wale": 0.5,
                        "nu_sgs_background": 0.0005, "launch_order": args.order or "library default",
                        "device_preheat_ms": args.preheat_ms,
@@ -295,7 +410,12 @@ def main():
                          "traffic_unit": "fabric-side bytes per launch (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE; Infinity-Cache hits included)",
                          "traffic_source": traffic_source, "source_digest": digest,
                          "rho_store": ("stored (boundary / interior part launches always store it)" if runner is not None else
-                                       "elided (reproduced on demand, DESIGN 3.1)" if not os.environ.get("LUDWIG_EAGER_RHO") else "eager")},
+                                       "elided (reproduced on demand, DESIGN 3.1)" if not os.environ.get("LUDWIG_EAGER_RHO") else "eager"),
+                         "kernel_ms_eager_rho": None if eager_ms is None else round(eager_ms, 4),
+                         "frac_eager_rho": None if eager_ms is None else round(ALGO_BYTES_PER_LUP * cells_per_rank / (eager_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "eager_rho_note": None if eager_ms is None else
+                                           (f"{args.eager_rho_steps} further steps after the timed region with rho stored by every step, the reference "
+                                            "kernel's store pattern (ludwig_level_set_rho_store); same kernel, same bits")},
         }
         if comm is not None:
             out["comm"] = comm
@@ -303,9 +423,15 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_size, args.cpu_seconds)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    # teardown in an order somebody chose (round 2 left it to interpreter shutdown; profiles/README.md "exit-time SIGSEGV"): device idle,
+    # torch's event / stream wrappers dropped, the process group (RCCL's streams and kernels) gone, and only then the level's memory
+    # and the CU-masked stream underneath them
+    del region, ev
+    if runner is not None:
+        runner.close(dist)
+    else:
+        torch.cuda.synchronize()
+        level.close()
     if not ok:
         raise SystemExit("state went non-finite or trivial during the benchmark")
 

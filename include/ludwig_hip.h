@@ -164,6 +164,12 @@ int  ludwig_level_block_order(const LudwigLevel *level, int32_t *ref_to_internal
  * sub-step ahead, rho is stored by every step. Geometry fields (obstacle, sponge, wall_dist) must be changed with
  * ludwig_level_upload, which also refreshes the per-block flags derived from them. */
 int  ludwig_level_field_ptr(const LudwigLevel *level, int field, void **device_ptr, size_t *bytes);
+/* Distance between two populations / components of a device array, in ELEMENTS: >= 512 * n_blocks. The library pads it off the
+ * distances at which 27 + 27 concurrent streams load MI355X's memory channels unevenly (a 5-20 % loss that depends on nothing but
+ * n_blocks); arrays passed through the ABI keep the reference's stride 512 * n_blocks (src/blocks.jl:118-150).
+ * With the block order above: element (cell, block b, component k) is at cell + 512 * ref_to_internal[b] + stride * k.
+ * LUDWIG_STRIDE_PAD_BLOCKS=n in the environment overrides the padding (0 = none). */
+int  ludwig_level_population_stride(const LudwigLevel *level, int64_t *elements);
 
 /* init_eq! (src/main.jl:109-134): f = f_temp = (f_old) = w_k, rho_old = 1, vel_old = 0 */
 int  ludwig_init_equilibrium(LudwigLevel *level);
@@ -227,6 +233,12 @@ int  ludwig_map_surface_stresses(const LudwigLevel *level, int vel_field, int32_
  * non-obstacle cells of the blocks this device owns, reduced on the device (+inf for a level without owned blocks). A
  * multi-GPU caller takes the minimum over ranks (one all-reduce MIN). */
 int  ludwig_level_rho_min(const LudwigLevel *level, float *rho_min);
+
+/* rho store policy. perform_timestep_v2!'s kernel writes rho for every cell on every step (src/physics_kernels.jl:243-246). By
+ * default a level nobody reads rho of between two steps skips that store and reproduces the array on demand, bit for bit (every
+ * reader inside the library asks for it). every_step = 1 restores the reference's store pattern on this level
+ * (LUDWIG_EAGER_RHO=1 in the environment does it for every level), 0 lets the library elide again. Results never depend on it. */
+int  ludwig_level_set_rho_store(LudwigLevel *level, int every_step);
 
 /* ---- halo exchange helpers (no reference counterpart: the reference is single-device) ---- */
 /* dst[i] = field[index[i]] / field[index[i]] = src[i]; index, dst, src are DEVICE pointers, index holds element

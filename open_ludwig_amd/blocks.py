@@ -310,6 +310,16 @@ class DeviceLevel:
         _lib.check(self._lib.ludwig_level_field_ptr(self.handle, _lib.FIELD_NAMES[name], C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def population_stride(self) -> int:
+        """elements between two populations / components of a device array (>= 512 n_blocks; only raw pointers see it)"""
+        v = C.c_int64()
+        _lib.check(self._lib.ludwig_level_population_stride(self.handle, C.byref(v)))
+        return int(v.value)
+
+    def set_rho_store(self, every_step: bool) -> None:
+        """True: rho is stored by every step like the reference's kernel (src/physics_kernels.jl:243-246); False: elided when unread"""
+        _lib.check(self._lib.ludwig_level_set_rho_store(self.handle, 1 if every_step else 0))
+
     def rho_min(self) -> float:
         """rho_min of compute_flow_stats (src/diagnostics.jl:56-94) over the owned, non-obstacle cells, reduced on the device"""
         v = C.c_float()

@@ -113,9 +113,12 @@ class DistributedStepper:
     def rho_min(self, level: int) -> float:
         lv = self.runner.levels[level]
         mine = lv.rho_min() if (lv is not None and self.runner.views[level].n_owned > 0) else float("inf")
-        t = self.torch.tensor([mine], dtype=self.torch.float32, device=self._comm_device())
+        # a diverged rank reports NaN (the reference's minimum() propagates it, src/diagnostics.jl:71); what MIN makes of a NaN is
+        # the backend's business, so it travels as a flag: [min of the finite values, -1 if any rank saw NaN], one all-reduce MIN
+        nan = mine != mine
+        t = self.torch.tensor([float("inf") if nan else mine, -1.0 if nan else 0.0], dtype=self.torch.float32, device=self._comm_device())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return float(t.item())
+        return float("nan") if float(t[1].item()) < 0 else float(t[0].item())
 
     def _triangle_map(self, level: int, mesh, params, search_radius: int):
         key = (level, search_radius)

@@ -1049,26 +1049,38 @@ __global__ __launch_bounds__(128) void k_map_stresses(const SurfaceParams s)
 }
 
 // ---- compute_flow_stats, reference src/diagnostics.jl:56-94 (CUDA branch): minimum of rho over non-obstacle cells ----
-// rho > 0 always (clamped at 0.01, obstacle cells hold 1), so the IEEE bit pattern orders like the value and an integer
+// Finite rho is > 0 (clamped at 0.01, obstacle cells hold 1), so the IEEE bit pattern orders like the value and an integer
 // atomicMin does the job; a minimum does not depend on the order of its operands: identical to any host reduction.
+// A diverged run holds NaN, and the reference's minimum() PROPAGATES it (Julia's min, like jl_max above) where fminf and the
+// integer compare would silently drop it: a NaN in any counted cell raises out[1], and the caller reports NaN.
 __global__ __launch_bounds__(256) void k_rho_min(const float *__restrict__ rho, const uint8_t *__restrict__ obstacle, int64_t n, int *__restrict__ out)
 {
     float m = __int_as_float(0x7f800000);   // +inf
+    bool nan = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        if (!obstacle[i]) m = fminf(m, rho[i]);
+        if (!obstacle[i]) {
+            const float v = rho[i];
+            nan = nan || v != v;
+            m = fminf(m, v);
+        }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMin(out, __float_as_int(m));
+    const bool any_nan = __any(nan);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(out, __float_as_int(m));
+        if (any_nan) atomicOr(out + 1, 1);
+    }
 }
 
 // ---- internal block order (ludwig_hip.hip "block order"): the caller's arrays keep the reference's block order, the device
 // arrays hold the blocks in the library's own order; ref2int[b_reference] = b_internal ----
 // element offset in the reference layout (cell + 512 b + 512 n_blocks k) -> the same element in the device array
-__device__ __forceinline__ int64_t to_internal_offset(int64_t off, const int32_t *__restrict__ ref2int, int64_t sk)
+// (sk_ref = 512 n_blocks: the caller's population stride; sk: the device array's)
+__device__ __forceinline__ int64_t to_internal_offset(int64_t off, const int32_t *__restrict__ ref2int, int64_t sk_ref, int64_t sk)
 {
-    if (!ref2int) return off;
-    const int64_t k = off / sk, r = off - k * sk;
-    return k * sk + (int64_t)ref2int[r >> 9] * CELLS + (r & 511);
+    if (!ref2int && sk == sk_ref) return off;
+    const int64_t k = off / sk_ref, r = off - k * sk_ref;
+    return k * sk + (ref2int ? (int64_t)ref2int[r >> 9] : (r >> 9)) * CELLS + (r & 511);
 }
 template <class T>
 __global__ __launch_bounds__(256) void k_blocks_to_internal(T *__restrict__ dst, const T *__restrict__ src, const int32_t *__restrict__ ref2int, int64_t n)
@@ -1085,16 +1097,16 @@ __global__ __launch_bounds__(256) void k_blocks_to_reference(T *__restrict__ dst
 
 // ---- halo pack / unpack: index holds element offsets in the REFERENCE layout ----
 __global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst,
-                         const int32_t *__restrict__ ref2int, int64_t sk)
+                         const int32_t *__restrict__ ref2int, int64_t sk_ref, int64_t sk)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = field[to_internal_offset(index[i], ref2int, sk)];
+    if (i < n) dst[i] = field[to_internal_offset(index[i], ref2int, sk_ref, sk)];
 }
 __global__ void k_scatter(float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, const float *__restrict__ src,
-                          const int32_t *__restrict__ ref2int, int64_t sk)
+                          const int32_t *__restrict__ ref2int, int64_t sk_ref, int64_t sk)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) field[to_internal_offset(index[i], ref2int, sk)] = src[i];
+    if (i < n) field[to_internal_offset(index[i], ref2int, sk_ref, sk)] = src[i];
 }
 
 }  // namespace lw

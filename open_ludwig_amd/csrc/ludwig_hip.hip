@@ -50,7 +50,12 @@ struct LudwigLevel {
     int level_id = 1, n_blocks = 0, n_owned = 0;
     float tau = 1.0f;
     int gdx = 0, gdy = 0, gdz = 0;
-    int64_t sk = 0;   // 512 * n_blocks
+    // Population stride. The caller's arrays are [8,8,8,n_blocks,K]: sk_ref = 512 * n_blocks elements between two populations
+    // (reference src/blocks.jl:118-150). The device arrays keep sk >= sk_ref elements between them (choose_stride_blocks below):
+    // 27 + 27 concurrent streams that far apart load MI355X's memory channels unevenly at some distances (5-20 % of the step,
+    // profiles/r02_population_stride_sweep.txt), and n_blocks is whatever the geometry gives. Translated at the ABI like the
+    // block order; only raw pointers see it (ludwig_level_population_stride).
+    int64_t sk = 0, sk_ref = 0;
     float *f[2] = {nullptr, nullptr};      // f, f_temp
     float *vel[2] = {nullptr, nullptr};    // vel, vel_temp
     float *rho = nullptr, *f_post = nullptr, *f_old = nullptr, *rho_old = nullptr, *vel_old = nullptr;
@@ -205,9 +210,10 @@ int before_external_write(LudwigLevel *L, int field)
     return hits ? materialize_old(L) : LUDWIG_OK;
 }
 
+// bytes = size of the field in the CALLER's layout (stride sk_ref); the device array is comps x sk elements
 FieldDesc field_desc(const LudwigLevel *L, int field)
 {
-    const size_t c = (size_t)L->sk;
+    const size_t c = (size_t)L->sk_ref;
     if (L->old_alias >= 0) {          // readers of the saved state follow the alias
         if (field == LUDWIG_F_OLD) return {L->f[L->old_alias], L->has_temporal ? c * Q * 4 : 0};
         if (field == LUDWIG_VEL_OLD) return {L->vel[L->old_alias], L->has_temporal ? c * 3 * 4 : 0};
@@ -815,31 +821,53 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
     return LUDWIG_OK;
 }
 
-// Host <-> device copy of a whole field between the caller's array (reference block order) and the device array (internal
-// order), one population / component at a time through `scratch`. es = element size (1: obstacle, else 4).
-int copy_field_permuted(LudwigLevel *L, void *dev, void *host, size_t bytes, size_t es, bool to_device)
+// Host <-> device copy of a whole field between the caller's array (reference block order, population stride sk_ref) and the
+// device array (internal block order, population stride sk). Same order and same stride: one copy; otherwise one population /
+// component at a time, through `scratch` and a block-permuting kernel when the orders differ. es = element size (1: obstacle,
+// 2: q map, else 4). Synchronous on the level's stream.
+int copy_field(LudwigLevel *L, void *dev, void *host, size_t bytes, size_t es, bool to_device)
 {
-    const size_t plane = (size_t)L->sk * es;                 // one population in bytes
-    const size_t K = bytes / plane;
-    if (!L->scratch) LW_HIP(hipMalloc(&L->scratch, (size_t)L->sk * 4));
-    const int64_t n = L->sk;
+    const size_t hplane = (size_t)L->sk_ref * es, dplane = (size_t)L->sk * es;     // one population in bytes, host / device
+    const size_t K = hplane ? bytes / hplane : 0;
+    const bool permute = !L->ref2int.empty();
+    if (!permute && (L->sk == L->sk_ref || K <= 1)) {
+        if (to_device) LW_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, L->stream));
+        else LW_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, L->stream));
+        LW_HIP(hipStreamSynchronize(L->stream));
+        return LUDWIG_OK;
+    }
+    if (permute && !L->scratch) LW_HIP(hipMalloc(&L->scratch, (size_t)L->sk_ref * 4));
+    const int64_t n = L->sk_ref;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     for (size_t k = 0; k < K; ++k) {
-        char *d = (char *)dev + k * plane, *h = (char *)host + k * plane;
-        if (to_device) {
-            LW_HIP(hipMemcpyAsync(L->scratch, h, plane, hipMemcpyHostToDevice, L->stream));
+        char *d = (char *)dev + k * dplane, *h = (char *)host + k * hplane;
+        if (!permute) {
+            if (to_device) LW_HIP(hipMemcpyAsync(d, h, hplane, hipMemcpyHostToDevice, L->stream));
+            else LW_HIP(hipMemcpyAsync(h, d, hplane, hipMemcpyDeviceToHost, L->stream));
+        } else if (to_device) {
+            LW_HIP(hipMemcpyAsync(L->scratch, h, hplane, hipMemcpyHostToDevice, L->stream));
             if (es == 1) hipLaunchKernelGGL(k_blocks_to_internal<uint8_t>, grid, block, 0, L->stream, (uint8_t *)d, (const uint8_t *)L->scratch, L->d_ref2int, n);
+            else if (es == 2) hipLaunchKernelGGL(k_blocks_to_internal<uint16_t>, grid, block, 0, L->stream, (uint16_t *)d, (const uint16_t *)L->scratch, L->d_ref2int, n);
             else hipLaunchKernelGGL(k_blocks_to_internal<float>, grid, block, 0, L->stream, (float *)d, (const float *)L->scratch, L->d_ref2int, n);
         } else {
             if (es == 1) hipLaunchKernelGGL(k_blocks_to_reference<uint8_t>, grid, block, 0, L->stream, (uint8_t *)L->scratch, (const uint8_t *)d, L->d_ref2int, n);
+            else if (es == 2) hipLaunchKernelGGL(k_blocks_to_reference<uint16_t>, grid, block, 0, L->stream, (uint16_t *)L->scratch, (const uint16_t *)d, L->d_ref2int, n);
             else hipLaunchKernelGGL(k_blocks_to_reference<float>, grid, block, 0, L->stream, (float *)L->scratch, (const float *)d, L->d_ref2int, n);
-            LW_HIP(hipMemcpyAsync(h, L->scratch, plane, hipMemcpyDeviceToHost, L->stream));
+            LW_HIP(hipMemcpyAsync(h, L->scratch, hplane, hipMemcpyDeviceToHost, L->stream));
             LW_HIP(hipStreamSynchronize(L->stream));          // pageable destination: the copy must be over before scratch is reused
         }
         LW_HIP(hipGetLastError());
     }
     LW_HIP(hipStreamSynchronize(L->stream));
     return LUDWIG_OK;
+}
+
+// Distance between two populations in device memory, in blocks (x 2 KiB): n_blocks plus padding. LUDWIG_STRIDE_PAD_BLOCKS=k
+// overrides the rule (0 = the reference's own stride).
+int64_t choose_stride_blocks(int64_t n_blocks)
+{
+    if (const char *e = getenv("LUDWIG_STRIDE_PAD_BLOCKS")) return n_blocks + std::max(0, atoi(e));
+    return n_blocks;
 }
 
 }  // namespace
@@ -995,8 +1023,9 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
     L->n_owned = n_owned;
     L->tau = h->tau;
     L->gdx = h->grid_dim_x; L->gdy = h->grid_dim_y; L->gdz = h->grid_dim_z;
-    L->sk = (int64_t)h->n_blocks * CELLS;
-    const size_t c = (size_t)L->sk, nb = (size_t)h->n_blocks;
+    L->sk_ref = (int64_t)h->n_blocks * CELLS;
+    L->sk = choose_stride_blocks(h->n_blocks) * CELLS;
+    const size_t c = (size_t)L->sk, cr = (size_t)L->sk_ref, nb = (size_t)h->n_blocks;
     L->has_temporal = h->enable_temporal_interpolation && nb > 0;            // reference src/blocks.jl:123
     L->bouzidi_enabled = h->n_boundary_cells > 0 && h->bouzidi_q_map;        // reference src/blocks.jl:152
     L->n_bc = L->bouzidi_enabled ? h->n_boundary_cells : 0;
@@ -1072,16 +1101,17 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             LW_HIP(hipMemsetAsync(L->vel_old, 0, c * 3 * 4, L->stream));
             if ((r = fill(L, L->rho_old, L->sk, 1.0f))) return r;
         }
-        if (h->obstacle) LW_HIP(hipMemcpyAsync(L->obstacle, h->obstacle, c, hipMemcpyHostToDevice, L->stream));
+        if (h->obstacle) LW_HIP(hipMemcpyAsync(L->obstacle, h->obstacle, cr, hipMemcpyHostToDevice, L->stream));
         else LW_HIP(hipMemsetAsync(L->obstacle, 0, c, L->stream));
-        if (h->sponge) LW_HIP(hipMemcpyAsync(L->sponge, h->sponge, c * 4, hipMemcpyHostToDevice, L->stream));
+        if (h->sponge) LW_HIP(hipMemcpyAsync(L->sponge, h->sponge, cr * 4, hipMemcpyHostToDevice, L->stream));
         else LW_HIP(hipMemsetAsync(L->sponge, 0, c * 4, L->stream));
-        if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, c * 4, hipMemcpyHostToDevice, L->stream));
+        if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, cr * 4, hipMemcpyHostToDevice, L->stream));
         else if ((r = fill(L, L->wall_dist, L->sk, 100.0f))) return r;
         // block_pointer stays on the host: its only use is the static corner lookup of a child's interface links
         if (h->block_pointer && nptr > 0) L->h_block_pointer.assign(h->block_pointer, h->block_pointer + nptr);
         if (L->bouzidi_enabled) {
-            LW_HIP(hipMemcpyAsync(L->q_map, h->bouzidi_q_map, c * Q * 2, hipMemcpyHostToDevice, L->stream));
+            for (int k = 0; k < Q; ++k)       // host: population stride sk_ref, device: sk
+                LW_HIP(hipMemcpyAsync(L->q_map + c * k, h->bouzidi_q_map + cr * k, cr * 2, hipMemcpyHostToDevice, L->stream));
             std::vector<int32_t> cb((size_t)L->n_bc);
             std::vector<int8_t> cx((size_t)L->n_bc), cy((size_t)L->n_bc), cz((size_t)L->n_bc);
             for (int i = 0; i < L->n_bc; ++i) {
@@ -1099,7 +1129,7 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             for (int i = 0; i < L->n_bc; ++i) {
                 const int own = cb[i] * CELLS + cx[i] + 8 * cy[i] + 64 * cz[i];
                 for (int k = 0; k < Q; ++k)
-                    if ((float)qh[(size_t)own + (size_t)c * k] > 0.0f) bl.push_back(make_int2(own, k));
+                    if ((float)qh[(size_t)own + cr * k] > 0.0f) bl.push_back(make_int2(own, k));
             }
             L->n_bouzidi_links = (int)bl.size();
             if (!bl.empty()) {
@@ -1233,12 +1263,9 @@ int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t byte
         if (r) return r;
     }
     const size_t es = field == LUDWIG_OBSTACLE ? 1 : 4;
-    if (!L->ref2int.empty()) {
-        const int r = copy_field_permuted(L, field_desc(L, field).ptr, const_cast<void *>(host), bytes, es, true);
+    {
+        const int r = copy_field(L, field_desc(L, field).ptr, const_cast<void *>(host), bytes, es, true);
         if (r) return r;
-    } else {
-        LW_HIP(hipMemcpyAsync(field_desc(L, field).ptr, host, bytes, hipMemcpyHostToDevice, L->stream));
-        LW_HIP(hipStreamSynchronize(L->stream));
     }
     if (field == LUDWIG_OBSTACLE || field == LUDWIG_SPONGE || field == LUDWIG_WALL_DIST) {
         if (!L->ref2int.empty()) {                             // the per-block flags are indexed by internal block id
@@ -1265,11 +1292,7 @@ int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t by
         const int r = ensure_rho(const_cast<LudwigLevel *>(L));
         if (r) return r;
     }
-    if (!L->ref2int.empty())
-        return copy_field_permuted(const_cast<LudwigLevel *>(L), d.ptr, host, bytes, field == LUDWIG_OBSTACLE ? 1 : 4, false);
-    LW_HIP(hipMemcpyAsync(host, d.ptr, bytes, hipMemcpyDeviceToHost, L->stream));
-    LW_HIP(hipStreamSynchronize(L->stream));
-    return LUDWIG_OK;
+    return copy_field(const_cast<LudwigLevel *>(L), d.ptr, host, bytes, field == LUDWIG_OBSTACLE ? 1 : 4, false);
 }
 
 int ludwig_level_block_order(const LudwigLevel *L, int32_t *ref_to_internal)
@@ -1295,7 +1318,28 @@ int ludwig_level_field_ptr(const LudwigLevel *L, int field, void **device_ptr, s
         m->rho_eager = true;
     }
     *device_ptr = d.ptr;
-    if (bytes) *bytes = d.bytes;
+    if (bytes) *bytes = L->sk_ref > 0 ? d.bytes / (size_t)L->sk_ref * (size_t)L->sk : d.bytes;   // the device array: comps x sk elements
+    return LUDWIG_OK;
+}
+
+int ludwig_level_set_rho_store(LudwigLevel *L, int every_step)
+{
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    if (every_step) {
+        const int r = ensure_rho(L);                // what the last step elided is produced now; from here on every step stores
+        if (r) return r;
+        L->rho_eager = true;
+    } else {
+        L->rho_eager = false;                       // steps may elide again; a reader that turns up twice in a row makes it eager again
+        L->last_replay_step = -10;
+    }
+    return LUDWIG_OK;
+}
+
+int ludwig_level_population_stride(const LudwigLevel *L, int64_t *elements)
+{
+    if (!L || !elements) return fail(LUDWIG_ERR_INVALID, "null argument");
+    *elements = L->sk;
     return LUDWIG_OK;
 }
 
@@ -1546,20 +1590,21 @@ int ludwig_level_rho_min(const LudwigLevel *L, float *rho_min)
         if (r) return r;
     }
     int *d = nullptr;
-    LW_HIP(hipMalloc((void **)&d, sizeof(int)));
-    const int inf_bits = 0x7f800000;
-    hipError_t e = hipMemcpyAsync(d, &inf_bits, sizeof(int), hipMemcpyHostToDevice, L->stream);
+    LW_HIP(hipMalloc((void **)&d, 2 * sizeof(int)));
+    const int init[2] = {0x7f800000, 0};                  // +inf, "no NaN seen"
+    hipError_t e = hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, L->stream);
     const int64_t n = (int64_t)L->n_owned * CELLS;
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_rho_min, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 2048)), dim3(256), 0, L->stream, L->rho, L->obstacle, n, d);
         e = hipGetLastError();
     }
-    int bits = inf_bits;
-    if (e == hipSuccess) e = hipMemcpyAsync(&bits, d, sizeof(int), hipMemcpyDeviceToHost, L->stream);
+    int res[2] = {init[0], 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d, sizeof res, hipMemcpyDeviceToHost, L->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(L->stream);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(LUDWIG_ERR_HIP, "rho_min: %s", hipGetErrorString(e));
-    memcpy(rho_min, &bits, sizeof(float));
+    memcpy(rho_min, &res[0], sizeof(float));
+    if (res[1]) *rho_min = __builtin_nanf("");            // minimum() of the reference propagates NaN (src/diagnostics.jl:71)
     return LUDWIG_OK;
 }
 
@@ -1578,7 +1623,7 @@ int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, 
         // the replay ran on the level's stream: a pack queued on another stream must not overtake it
         if (stale && hip_stream && (hipStream_t)hip_stream != L->stream) LW_HIP(hipStreamSynchronize(L->stream));
     }
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev, (const int32_t *)L->d_ref2int, L->sk);
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev, (const int32_t *)L->d_ref2int, L->sk_ref, L->sk);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -1597,7 +1642,7 @@ int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int6
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be unpacked", field);
     LW_HIP(hipSetDevice(L->device));
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev, (const int32_t *)L->d_ref2int, L->sk);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev, (const int32_t *)L->d_ref2int, L->sk_ref, L->sk);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }

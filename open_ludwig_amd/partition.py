@@ -417,31 +417,6 @@ def rank_grid(world: int) -> Tuple[int, int, int]:
     return tuple(g)
 
 
-def stride_padding_blocks(n_local: int, owner: np.ndarray, rank: int, present: np.ndarray) -> np.ndarray:
-    """Extra remote blocks (global ids) to keep as never-read ghost copies, only to move the level's block count - i.e. the distance
-    between two populations in device memory, n_blocks x 2 KiB - off the values at which the stepping kernel loses 5-17 % on MI355X
-    (27 + 27 streams that far apart hit the memory channels unevenly; `profiles/r02_population_stride_sweep.txt`: 68 MiB costs the
-    plain box 10-17 %, and a 2-rank brick of 256^3 cells lands exactly there: loop-back 0.93 -> 0.87 ms per step when moved to 69).
-    Only that value is in the table: the other spikes of the sweep (76-77, 83, 86, 90 MiB) gave nothing consistent when the 8-rank
-    views (76.5-76.8 MiB) were moved off them (`r02_rccl_loopback_8_rank_padding_targets.txt`).
-    LUDWIG_VIEW_PAD_BLOCKS=n overrides the table (0 = no padding)."""
-    env = os.environ.get("LUDWIG_VIEW_PAD_BLOCKS")
-    if env is not None:
-        pad = int(env)
-    else:
-        mib = n_local / 512.0
-        bad = ((67.5, 68.5, 69.0),)     # (from, to, go to) in MiB
-        pad = 0
-        for lo, hi, to in bad:
-            if lo <= mib <= hi:
-                pad = int(round(to * 512)) - n_local
-    if pad <= 0:
-        return np.zeros(0, np.int64)
-    cand = np.flatnonzero(owner != rank)
-    cand = cand[~np.isin(cand, present)]
-    return cand[:pad]
-
-
 def periodic_box_topology(nb_global: Tuple[int, int, int], grid: Tuple[int, int, int]):
     """coords (reference order), periodic neighbor_table and the brick owner of every block."""
     nbx, nby, nbz = nb_global
@@ -572,8 +547,26 @@ class DistributedLevelRunner:
         self.flush()
         self.torch.cuda.synchronize(self.dev)
 
-    def close(self) -> None:
+    def close(self, dist=None) -> None:
+        """Teardown in a fixed order: (1) everything queued has run, (2) torch's wrappers of our streams and the events recorded on
+        them are dropped, (3) the process group - RCCL's communicator, its streams and whatever it still holds of ours - is
+        destroyed (pass torch.distributed as `dist` when this runner is the last user of the default group), (4) the level's device
+        memory is freed, (5) the CU-masked stream underneath is destroyed. Round 2 destroyed the stream first, under live
+        ExternalStream wrappers and a live communicator, and left the rest to interpreter shutdown: one profiled run ended in a
+        SIGSEGV inside __cxa_finalize (profiles/README.md)."""
+        import gc
         self.synchronize()
+        self.ex._events = []
+        self.ex = None
+        self.ev_boundary = self.ev_exchanged = self.ev_post = self.ev_post_done = None
+        self.level.set_stream(None)
+        self.s_comm = None
+        self.s_comp = None
+        gc.collect()
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        self.torch.cuda.synchronize(self.dev)
         self.level.close()
         for ptr in self._own_streams:
             self._lib.check(self._lib.load().ludwig_stream_destroy(self.dev.index, self.C.c_void_p(ptr)))
@@ -931,29 +924,55 @@ def weak_scaling_layout(world: int, nb: int) -> Tuple[Tuple[int, int, int], Tupl
     return (nb, nb, nb), rank_grid(world)
 
 
-def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int, int], device: int, overlap: bool = True,
-                              order: Optional[str] = None, stage_through_host: bool = False, tau: float = 0.5006, u0: float = 0.03,
-                              grid: Optional[Tuple[int, int, int]] = None):
-    """bench.py N > 1 workload: every rank owns an nb_per_rank brick of one periodic Taylor-Green box cut into `grid` ranks
-    (default rank_grid(world); bench.py: weak_scaling_layout - 8 ranks x 32^3 blocks = BASELINE configs[3], 512^3 cells)."""
+def strong_scaling_layout(world: int, nb_global: int) -> Tuple[Tuple[int, int, int], Tuple[int, int, int]]:
+    """(blocks per rank along x, y, z; ranks along x, y, z) for a FIXED global box of nb_global^3 blocks (bench.py --scaling strong;
+    BASELINE configs[3]: the 512^3 box at 1 / 2 / 4 / 8 GPUs). Cuts as in weak_scaling_layout: z first, then y, never x while the
+    bricks stay at least 4 blocks thick (an x face is single cells 32 B apart and breaks the runs of x-consecutive blocks):
+    1 -> 1x1x1, 2 -> 1x1x2, 4 -> 1x2x2, 8 -> 1x2x4, 16 -> 1x4x4."""
+    g = [1, 1, 1]
+    w, a = world, 0
+    while w > 1:
+        if w % 2:
+            raise ValueError("world size must be a power of two")
+        g[2 - a % 2] *= 2                 # z, y, z, y ...
+        w //= 2
+        a += 1
+    if any(nb_global % gi for gi in g) or min(nb_global // g[1], nb_global // g[2]) < 4:
+        raise ValueError(f"a box of {nb_global}^3 blocks cannot be cut {g[0]}x{g[1]}x{g[2]}")
+    return (nb_global // g[0], nb_global // g[1], nb_global // g[2]), tuple(g)
+
+
+def periodic_box_plan(rank: int, world: int, nb_per_rank: Tuple[int, int, int], grid: Tuple[int, int, int], tau: float = 0.5006,
+                      u0: float = 0.03, init: bool = True):
+    """Host side of bench.py's N > 1 workload, no GPU needed: rank `rank`'s view of a periodic Taylor-Green box cut into `grid`
+    bricks of nb_per_rank blocks, its halo plan (requests exchanged over the default process group) and the step parameters."""
     from . import cases
     from .physics import SolverParams
-    grid = tuple(grid) if grid is not None else rank_grid(world)
+    grid = tuple(grid)
     assert grid[0] * grid[1] * grid[2] == world
     nbg = tuple(nb_per_rank[i] * grid[i] for i in range(3))
     coords, table, owner = periodic_box_topology(nbg, grid)
     widen = os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0"
     view = build_local_level(1, coords, table, owner, rank, tau, widen_x_runs=widen)
-    extra = stride_padding_blocks(view.level.n_blocks, owner, rank, view.local_to_global)
-    if len(extra):
-        view = build_local_level(1, coords, table, owner, rank, tau, widen_x_runs=widen, extra_ghosts=extra)
-    cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), u0, share_ab_buffers=True)    # host level is only uploaded
+    if init:
+        cases.init_taylor_green(view.level, tuple(8 * n for n in nbg), u0, share_ab_buffers=True)    # host level is only uploaded
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)
     n_global = len(coords)
     mine = make_requests(view, n_global)
     to_me = exchange_requests(mine, world, rank) if world > 1 else ({rank: mine[rank]} if rank in mine else {})
     plan = build_plan(view, n_global, mine, to_me)
+    return view, plan, params, n_global
+
+
+def periodic_weak_scaling_box(rank: int, world: int, nb_per_rank: Tuple[int, int, int], device: int, overlap: bool = True,
+                              order: Optional[str] = None, stage_through_host: bool = False, tau: float = 0.5006, u0: float = 0.03,
+                              grid: Optional[Tuple[int, int, int]] = None):
+    """bench.py N > 1 workload: every rank owns an nb_per_rank brick of one periodic Taylor-Green box cut into `grid` ranks
+    (default rank_grid(world); bench.py: weak_scaling_layout - 8 ranks x 32^3 blocks = BASELINE configs[3], 512^3 cells - or
+    strong_scaling_layout for a fixed global box)."""
+    grid = tuple(grid) if grid is not None else rank_grid(world)
+    view, plan, params, n_global = periodic_box_plan(rank, world, nb_per_rank, grid, tau, u0)
     runner = DistributedLevelRunner(view, plan, params, device, overlap=overlap, stage_through_host=stage_through_host, order=order)
     runner.n_global_blocks = n_global
     return runner

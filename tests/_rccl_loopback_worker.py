@@ -36,9 +36,6 @@ def symmetric_brick_plan(grid, nb, upload_only=True):
     coords, table, owner = partition.periodic_box_topology(nbg, grid)
     widen = os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0"
     view = partition.build_local_level(1, coords, table, owner, 0, 0.5006, widen_x_runs=widen)
-    extra = partition.stride_padding_blocks(view.level.n_blocks, owner, 0, view.local_to_global)      # as the bench path does
-    if len(extra):
-        view = partition.build_local_level(1, coords, table, owner, 0, 0.5006, widen_x_runs=widen, extra_ghosts=extra)
     cases.init_taylor_green(view.level, tuple(8 * n for n in nb3), 0.03, share_ab_buffers=upload_only)      # period = one brick
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)
@@ -109,6 +106,7 @@ def main():
         rep["skipped"] = sorted(skip)
     rep["peers"] = len(plan.peers)
     rep["view_blocks"] = int(view.level.n_blocks)
+    rep["stride_blocks"] = runner.level.population_stride() // 512
     rep["halo_bytes_per_step"] = plan.bytes_per_step()
     # ghosts of the start state: sin(x + one period) is not bit-equal to sin(x) in floating point, so fetch them the same way
     runner.ex.exchange("f", "vel")
@@ -156,11 +154,10 @@ def main():
         torch.cuda.synchronize()
         rep["identical"] = {n: bool(np.array_equal(got[n], single.download(n)[:, :, :, sel])) for n in (fn, vn, "rho")}
         rep["moved"] = bool(got[vn].std() > 0)
+        single.close()
     json.dump(rep, open(out_path, "w"))
     print(json.dumps(rep), flush=True)
-    runner.close()
-    dist.barrier()
-    dist.destroy_process_group()
+    runner.close(dist)          # device idle -> wrappers dropped -> process group destroyed -> level freed -> masked stream destroyed
 
 
 if __name__ == "__main__":

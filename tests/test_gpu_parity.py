@@ -380,7 +380,7 @@ def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
     inv = np.argsort(order)                                          # internal position -> reference block
     patch_ref = f_new[..., 5] * np.float32(1.01)                     # (8,8,8,nb) in the reference order
     patch = np.ascontiguousarray(patch_ref[:, :, :, inv].reshape(-1, order="F"))
-    assert hip.hipMemcpy(C.c_void_p(ptr + 5 * grids[0].rho.size * 4), patch.ctypes.data, patch.nbytes, 1) == 0   # host -> device
+    assert hip.hipMemcpy(C.c_void_p(ptr + 5 * dev[0].population_stride() * 4), patch.ctypes.data, patch.nbytes, 1) == 0   # host -> device
     perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 2 * t + 1, np.float32(0.5))
     got, got_old = dev[1].download("f"), dev[0].download("f_old")
 
@@ -488,3 +488,61 @@ def test_stepping_stream_with_reserved_compute_units(gpu):
     plain = C.c_void_p()
     _lib.check(lib.ludwig_stream_create(0, 0, C.byref(plain)))            # 0 reserved: an ordinary stream
     _lib.check(lib.ludwig_stream_destroy(0, plain))
+
+
+@pytest.mark.parametrize("pad", ["3", "40"])
+def test_padded_population_stride_gives_the_same_bits(gpu, monkeypatch, pad):
+    """The device arrays may keep more than 512 n_blocks elements between two populations (ludwig_level_population_stride; the
+    library pads n_blocks off the distances that load MI355X's memory channels unevenly). Everything that crosses the ABI keeps
+    the reference's stride: a 3-level wall-model tunnel with Bouzidi cells stepped with a forced padding (every array, the q map,
+    the parents' interpolation reads, upload / download) equals the oracle bit for bit; halo pack / unpack address the same cells."""
+    import ctypes as C
+    import torch
+    from open_ludwig_amd import _lib
+    monkeypatch.setenv("LUDWIG_STRIDE_PAD_BLOCKS", pad)
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)
+    dev = run_both(grids, params, 4, 0.05, batch=3)
+    for g, d in zip(grids, dev):
+        assert d.population_stride() == 512 * (g.n_blocks + int(pad))
+        assert d.field_ptr("vel")[1] == 3 * 4 * d.population_stride()
+    # pack / unpack take element offsets of the REFERENCE layout: pick population 5 of 100 cells scattered over level 2
+    d, g = dev[1], grids[1]
+    fn, _ = oracle.newest_buffers(1, 4)
+    rng = np.random.default_rng(3)
+    off = np.sort(rng.choice(g.n_blocks * 512, 100, replace=False)) + 5 * g.n_blocks * 512
+    idx = torch.as_tensor(off, dtype=torch.int64, device="cuda")
+    buf = torch.empty(100, dtype=torch.float32, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.ludwig_halo_pack(d.handle, _lib.FIELD_NAMES[fn], C.c_void_p(idx.data_ptr()), 100, C.c_void_p(buf.data_ptr()), None))
+    d.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), getattr(g, fn).reshape(-1, order="F")[off])
+    buf.mul_(2.0)
+    torch.cuda.synchronize()
+    _lib.check(lib.ludwig_halo_unpack(d.handle, _lib.FIELD_NAMES[fn], C.c_void_p(idx.data_ptr()), 100, C.c_void_p(buf.data_ptr()), None))
+    d.synchronize()
+    want = getattr(g, fn).copy(order="F")
+    want.reshape(-1, order="F")[off] *= np.float32(2.0)
+    assert np.array_equal(d.download(fn), want)
+    d.upload(fn, getattr(g, fn))
+    compare(grids, dev, 4)
+
+
+def test_rho_min_propagates_nan_like_the_reference(gpu):
+    """compute_flow_stats takes minimum(rho[.!obstacle]) (src/diagnostics.jl:71), and Julia's minimum propagates NaN: a diverged run
+    must not print a finite rho_min. NaN in a fluid cell -> NaN; NaN in an obstacle cell is not counted."""
+    grids, params = cases.tunnel_with_sphere((5, 3, 3), levels=1)
+    g = grids[0]
+    d = adapt(g, 0)
+    rho = np.asfortranarray(1.0 + 0.01 * np.random.default_rng(1).random(g.rho.shape, dtype=np.float32))
+    d.upload("rho", rho)
+    assert d.rho_min() == float(rho[~g.obstacle].min())
+    fluid = np.argwhere(~g.obstacle)[17]
+    solid = np.argwhere(g.obstacle)[3]
+    bad = rho.copy(order="F")
+    bad[tuple(solid)] = np.nan
+    d.upload("rho", bad)
+    assert d.rho_min() == float(rho[~g.obstacle].min())
+    bad[tuple(fluid)] = np.nan
+    d.upload("rho", bad)
+    assert np.isnan(d.rho_min())
+    d.close()

@@ -224,23 +224,6 @@ def test_widened_boundary_part_keeps_whole_x_runs():
     assert not (ghosty & ~b).any()
 
 
-def test_stride_padding_moves_a_view_off_the_bad_block_counts(monkeypatch):
-    """partition.stride_padding_blocks: remote blocks kept as never-read ghost copies so that n_blocks x 2 KiB - the distance between
-    two populations - leaves the values measured as bad on MI355X (68 MiB: a 2-rank brick of 256^3 cells). Small views, views at
-    good strides and an explicit 0 get nothing; the extra blocks are remote and not present yet."""
-    monkeypatch.delenv("LUDWIG_VIEW_PAD_BLOCKS", raising=False)
-    owner = np.array([0] * 34000 + [1] * 6000)
-    present = np.arange(34816)                       # 34 000 owned + 816 ghosts of rank 1 = 68.0 MiB
-    extra = partition.stride_padding_blocks(34816, owner, 0, present)
-    assert len(extra) == 69 * 512 - 34816 and (owner[extra] == 1).all() and not np.isin(extra, present).any()
-    assert len(partition.stride_padding_blocks(36992, owner, 0, present)) == 0          # 72.25 MiB: fine as it is
-    assert len(partition.stride_padding_blocks(1000, owner, 0, present)) == 0
-    monkeypatch.setenv("LUDWIG_VIEW_PAD_BLOCKS", "0")
-    assert len(partition.stride_padding_blocks(34816, owner, 0, present)) == 0
-    monkeypatch.setenv("LUDWIG_VIEW_PAD_BLOCKS", "7")
-    assert len(partition.stride_padding_blocks(1000, owner, 0, present)) == 7
-
-
 def test_weak_scaling_layout_keeps_the_cells_per_rank_and_the_global_box():
     """bench.py's N > 1 boxes: nb^3 blocks per rank for every world size; 8 ranks = the (2 nb)^3 box (BASELINE configs[3]) cut
     1 x 2 x 4 - no x face; 2 and 4 ranks cut z, then y."""
@@ -250,6 +233,19 @@ def test_weak_scaling_layout_keeps_the_cells_per_rank_and_the_global_box():
     assert partition.weak_scaling_layout(8, 32) == ((64, 32, 16), (1, 2, 4))
     assert tuple(b * g for b, g in zip(*partition.weak_scaling_layout(8, 32))) == (64, 64, 64)
     assert partition.weak_scaling_layout(2, 32) == ((32, 32, 32), (1, 1, 2)) and partition.weak_scaling_layout(4, 32)[1] == (1, 2, 2)
+
+
+def test_strong_scaling_layout_keeps_the_global_box():
+    """bench.py --scaling strong: BASELINE configs[3], the SAME 512^3 box (64^3 blocks) at 1 / 2 / 4 / 8 ranks, z and y cuts only."""
+    want = {1: ((64, 64, 64), (1, 1, 1)), 2: ((64, 64, 32), (1, 1, 2)), 4: ((64, 32, 32), (1, 2, 2)), 8: ((64, 32, 16), (1, 2, 4))}
+    for world, (brick, grid) in want.items():
+        assert partition.strong_scaling_layout(world, 64) == (brick, grid)
+        assert tuple(b * g for b, g in zip(brick, grid)) == (64, 64, 64)
+    assert partition.strong_scaling_layout(8, 64) == partition.weak_scaling_layout(8, 32)      # the two modes meet at configs[3]
+    with pytest.raises(ValueError):
+        partition.strong_scaling_layout(3, 64)
+    with pytest.raises(ValueError):
+        partition.strong_scaling_layout(8, 8)            # bricks thinner than an x-run
 
 
 def test_eight_rank_layout_has_three_equal_face_peers_and_no_x_face():
