@@ -181,12 +181,11 @@ def plan_only(args, world, rank, brick, rgrid, json_fd) -> None:
 
 
 def kernel_label(info) -> str:
-    """the stepping kernel exactly as rocprofv3 --kernel-trace --stats prints it (profiles/*_kernel_stats.csv can be joined on it)"""
-    nw = 8 if os.environ.get("LUDWIG_XRUN") == "8" else 4
-    if os.environ.get("LUDWIG_NO_XRUN"):
-        return "void lw::k_stream_collide<false, false, false>(lw::SCParams)"
+    """the stepping kernel exactly as rocprofv3 --kernel-trace --stats prints it (profiles/*_kernel_stats.csv can be joined on it):
+    template arguments NW, GENERAL, POST, WALL, RHO_ONLY, WIDE (64-bit per-lane addresses: levels whose f array is 4 GiB or more)"""
     general = "true" if info.n_general_blocks > 0 and info.n_fast_blocks == 0 else "false"
-    return f"void lw::k_stream_collide_xrun<{nw}, {general}, false, false, false>(lw::SCParams)"
+    wide = "true" if (info.n_blocks * 27 * 2048 >= 2 ** 32 or os.environ.get("LUDWIG_WIDE_ADDR")) else "false"
+    return f"void lw::k_stream_collide_xrun<4, {general}, false, false, false, {wide}>(lw::SCParams)"
 
 
 def main():
@@ -378,7 +377,7 @@ def main():
                 elif tj.get("source_digest") != digest:
                     traffic_source = (f"profiles/traffic.json was captured with sources {tj.get('source_digest')}, the loaded library is {digest}: "
                                       "stale, not reported")
-                elif args.order or world > 1 or os.environ.get("LUDWIG_XRUN") or os.environ.get("LUDWIG_EAGER_RHO"):
+                elif args.order or world > 1 or os.environ.get("LUDWIG_WIDE_ADDR") or os.environ.get("LUDWIG_EAGER_RHO"):
                     traffic_source = "profiles/traffic.json is for the default single-GPU launch: not reported for this configuration"
                 else:
                     traffic = tj.get("hbm_bytes_per_launch")

@@ -139,8 +139,8 @@ int  ludwig_stream_destroy(int device, void *hip_stream);
  * and z in 0..7 = the 8x8 z-plane of that block the wave steps; a negative item is an idle wave. Every
  * (block, plane) of the part must appear exactly once. Purely a performance knob (L2 / Infinity-Cache
  * locality); results do not depend on it. Default: x-runs, plane-per-XCD, see DESIGN.md.
- * What the library makes of the list: XRUN (4; 8 with LUDWIG_XRUN=8) consecutive items form one workgroup, and workgroup
- * g is expected on XCD g % 8. A group of XRUN items whose blocks are all of one kind (all 26 neighbours present, or all
+ * What the library makes of the list: 4 consecutive items form one workgroup, and workgroup
+ * g is expected on XCD g % 8. A group of 4 items whose blocks are all of one kind (all 26 neighbours present, or all
  * with a missing neighbour) keeps its composition and its slot; items of mixed or incomplete groups are re-packed behind
  * them. Neighbouring items of a group that hold x-adjacent blocks at the same plane exchange their face column through
  * LDS. Levels below 8 192 owned blocks step both kinds in one launch (LUDWIG_MERGE_CLASSES overrides).
@@ -164,12 +164,13 @@ int  ludwig_level_block_order(const LudwigLevel *level, int32_t *ref_to_internal
  * sub-step ahead, rho is stored by every step. Geometry fields (obstacle, sponge, wall_dist) must be changed with
  * ludwig_level_upload, which also refreshes the per-block flags derived from them. */
 int  ludwig_level_field_ptr(const LudwigLevel *level, int field, void **device_ptr, size_t *bytes);
-/* Distance between two populations / components of a device array, in ELEMENTS: >= 512 * n_blocks. The library pads it off the
- * distances at which 27 + 27 concurrent streams load MI355X's memory channels unevenly (a 5-20 % loss that depends on nothing but
- * n_blocks); arrays passed through the ABI keep the reference's stride 512 * n_blocks (src/blocks.jl:118-150).
- * With the block order above: element (cell, block b, component k) is at cell + 512 * ref_to_internal[b] + stride * k.
- * LUDWIG_STRIDE_PAD_BLOCKS=n in the environment overrides the padding (0 = none). */
-int  ludwig_level_population_stride(const LudwigLevel *level, int64_t *elements);
+/* Layout of a device array, for raw pointers: the device arrays are BLOCK-major - element (cell, block b, component k) of a field
+ * with K components lives at cell + component_stride * k + block_stride * ref_to_internal[b], with component_stride = 512 and
+ * block_stride = 512 K (the 27 populations of a block are one contiguous 54-KiB piece), whereas every array passed through the ABI
+ * keeps the reference's [8,8,8,n_blocks,K] (src/blocks.jl:118-150: components 512 n_blocks apart). Why: 27 + 27 concurrent streams
+ * n_blocks x 2 KiB apart load MI355X's memory system unevenly at distances that depend on nothing but n_blocks.
+ * Strides in ELEMENTS; any output pointer may be NULL. */
+int  ludwig_level_field_layout(const LudwigLevel *level, int field, int32_t *components, int64_t *block_stride, int64_t *component_stride);
 
 /* init_eq! (src/main.jl:109-134): f = f_temp = (f_old) = w_k, rho_old = 1, vel_old = 0 */
 int  ludwig_init_equilibrium(LudwigLevel *level);
@@ -248,6 +249,68 @@ int  ludwig_halo_pack(const LudwigLevel *level, int field, const int64_t *index_
                       float *dst_dev, void *hip_stream);
 int  ludwig_halo_unpack(LudwigLevel *level, int field, const int64_t *index_dev, int64_t n,
                         const float *src_dev, void *hip_stream);
+
+/* ---- multi-GPU: communicator, halo plan, exchange, distributed step (no reference counterpart: the reference is single-device,
+ * src/main.jl:75; its caller for this path is execute_timestep_batch!, src/solver_control.jl:145-165, which a multi-GPU host calls
+ * once per rank) ----
+ * One process per GPU. RCCL (ncclSend / ncclRecv, point-to-point over xGMI) is resolved at run time from the librccl already mapped
+ * into the process (e.g. PyTorch's) so that two copies never coexist; otherwise librccl.so(.1) is opened from the loader's path
+ * (LUDWIG_RCCL_LIB overrides). The library does not link against it: single-GPU users never load it. */
+typedef struct LudwigComm LudwigComm;
+#define LUDWIG_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: called by ONE rank; the host carries the 128 bytes to the others by its own means (MPI, a file, a socket). */
+int  ludwig_comm_unique_id(void *id_out);
+/* ncclCommInitRank on `device` (collective over the `world` ranks). */
+int  ludwig_comm_create(const void *unique_id, int rank, int world, int device, LudwigComm **out);
+void ludwig_comm_destroy(LudwigComm *comm);
+/* in-place all-reduce of a few Float32 scalars over the communicator (diagnostics: rho_min, force sums); op: 0 sum, 2 max, 3 min;
+ * buf is a HOST array. NaN in any rank's value gives NaN for min / max (the reference's minimum() propagates it). */
+int  ludwig_comm_allreduce_f32(LudwigComm *comm, float *buf, int32_t n, int32_t op);
+
+/* The ghost elements of one level this rank receives after a step and the owned elements it sends, per peer and per logical field
+ * GROUP: 0 = populations (f or f_temp), 1 = velocity (vel or vel_temp), 2 = f_post_collision, 3 = rho. For every group the lists of
+ * all peers are concatenated in peer order: index[count[0] + ... + count[p-1] ...] belongs to peer p. Element offsets are in the
+ * REFERENCE layout of the level (cell + 512 b + 512 n_blocks k); a peer's receive list and the matching send list of that peer name
+ * the same elements in the same order. Everything is translated and uploaded here, once: a step then costs three enqueue calls. */
+#define LUDWIG_HALO_GROUPS 4
+typedef struct LudwigHaloPlanDesc {
+    int32_t n_peers;
+    const int32_t *peer_ranks;                          /* [n_peers] rank in the communicator; this rank itself = a device copy   */
+    const int64_t *send_count[LUDWIG_HALO_GROUPS];      /* [n_peers] each; NULL = the group is empty                              */
+    const int64_t *recv_count[LUDWIG_HALO_GROUPS];
+    const int64_t *send_index[LUDWIG_HALO_GROUPS];      /* HOST arrays, concatenated over peers                                   */
+    const int64_t *recv_index[LUDWIG_HALO_GROUPS];
+} LudwigHaloPlanDesc;
+typedef struct LudwigHaloPlan LudwigHaloPlan;
+/* comm may be NULL when every peer is this rank itself (periodic wrap onto the own brick; tests). */
+int  ludwig_halo_plan_create(LudwigLevel *level, LudwigComm *comm, const LudwigHaloPlanDesc *desc, LudwigHaloPlan **out);
+void ludwig_halo_plan_destroy(LudwigHaloPlan *plan);
+
+/* One exchange: for i < n: group groups[i] of the plan moves field fields[i] (a LudwigField with as many components as the group).
+ * Queued on the plan's own HIGH-priority stream behind everything queued on the level's stream so far: pack (one kernel per group)
+ * -> ncclGroupStart, one ncclSend / ncclRecv per peer and group, ncclGroupEnd -> unpack. Returns at once; nothing queued on the
+ * level's stream LATER waits for it until ludwig_halo_wait, so work that reads no ghost can run under it. */
+int  ludwig_halo_exchange(LudwigHaloPlan *plan, int32_t n, const int32_t *groups, const int32_t *fields);
+/* everything queued on the level's stream after this call runs after the plan's last exchange */
+int  ludwig_halo_wait(LudwigHaloPlan *plan);
+/* For hosts that carry the messages themselves (a transport other than RCCL; the one-GPU rehearsals over gloo): the two halves of an
+ * exchange on `hip_stream` (NULL = the level's), and the message buffers (DEVICE pointers, Float32, peers concatenated as in the plan). */
+int  ludwig_halo_plan_pack(LudwigHaloPlan *plan, int32_t group, int32_t field, void *hip_stream);
+int  ludwig_halo_plan_unpack(LudwigHaloPlan *plan, int32_t group, int32_t field, void *hip_stream);
+int  ludwig_halo_plan_buffers(const LudwigHaloPlan *plan, int32_t group, void **send_dev, int64_t *n_send, void **recv_dev, int64_t *n_recv);
+/* Benchmarks: with timing on, every ludwig_halo_exchange is bracketed by events on the plan's stream (the span includes waiting beside
+ * whatever the device is busy with); ludwig_halo_plan_exchange_ms returns the spans of the exchanges finished since the last call
+ * (at most `max`, oldest first; call after a device synchronize). */
+int  ludwig_halo_plan_timing(LudwigHaloPlan *plan, int enable);
+int  ludwig_halo_plan_exchange_ms(LudwigHaloPlan *plan, float *ms_out, int32_t max, int32_t *n_out);
+
+/* perform_timestep_v2! (src/physics_v2.jl:26-97) of a level whose blocks are spread over ranks, with the exchange hidden behind
+ * compute: interior blocks of step t_sub (they read no ghost) -> wait for the exchange of the previous step -> boundary blocks
+ * -> [f_post_collision halo of the links that reach across a cut, Bouzidi correction] -> exchange of this step's output (groups 0
+ * and 1: the populations and velocity buffer step t_sub wrote), left in flight under the next call's interior blocks.
+ * ludwig_halo_wait (or the next call) joins it; ludwig_sync waits for the device. Same arguments as ludwig_step. */
+int  ludwig_step_distributed(LudwigLevel *level, LudwigHaloPlan *plan, const LudwigLevel *parent, int64_t t_sub, float u_curr,
+                             float parent_tau, float temporal_weight, const LudwigStepFlags *flags);
 
 /* ---- introspection for benchmarks ---- */
 typedef struct LudwigLevelInfo {

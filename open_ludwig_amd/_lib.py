@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "ludwig_init_equilibrium", "ludwig_step", "ludwig_stream_collide", "ludwig_bouzidi_correction",
     "ludwig_save_old", "ludwig_execute_timestep_batch", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
     "ludwig_map_surface_stresses", "ludwig_level_rho_min", "ludwig_level_block_order",
-    "ludwig_stream_create", "ludwig_stream_destroy", "ludwig_level_population_stride", "ludwig_level_set_rho_store",
+    "ludwig_stream_create", "ludwig_stream_destroy", "ludwig_level_field_layout", "ludwig_level_set_rho_store",
 ]
 
 
@@ -118,7 +118,7 @@ def load() -> C.CDLL:
         "ludwig_level_block_order": (C.c_int, [vp, vp]),
         "ludwig_stream_create": (C.c_int, [i32, i32, C.POINTER(vp)]),
         "ludwig_stream_destroy": (C.c_int, [i32, vp]),
-        "ludwig_level_population_stride": (C.c_int, [vp, C.POINTER(C.c_int64)]),
+        "ludwig_level_field_layout": (C.c_int, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "ludwig_level_set_rho_store": (C.c_int, [vp, i32]),
     }
     for name, (res, args) in sig.items():

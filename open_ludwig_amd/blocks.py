@@ -310,11 +310,11 @@ class DeviceLevel:
         _lib.check(self._lib.ludwig_level_field_ptr(self.handle, _lib.FIELD_NAMES[name], C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def population_stride(self) -> int:
-        """elements between two populations / components of a device array (>= 512 n_blocks; only raw pointers see it)"""
-        v = C.c_int64()
-        _lib.check(self._lib.ludwig_level_population_stride(self.handle, C.byref(v)))
-        return int(v.value)
+    def field_layout(self, name: str) -> Tuple[int, int, int]:
+        """(components K, block stride, component stride) of a device array in elements - block-major storage; only raw pointers see it"""
+        k, bs, cs = C.c_int32(), C.c_int64(), C.c_int64()
+        _lib.check(self._lib.ludwig_level_field_layout(self.handle, _lib.FIELD_NAMES[name], C.byref(k), C.byref(bs), C.byref(cs)))
+        return int(k.value), int(bs.value), int(cs.value)
 
     def set_rho_store(self, every_step: bool) -> None:
         """True: rho is stored by every step like the reference's kernel (src/physics_kernels.jl:243-246); False: elided when unread"""

@@ -13,6 +13,12 @@
 // blocks, which the library keeps consecutive in memory, see ludwig_hip.hip "Block order"). The block index and z
 // are wave-uniform, so the 27 neighbour block ids come through the scalar cache and each population load is one
 // coalesced, aligned 256-B access; the +-1 shift in x is a lane shift plus an LDS column between neighbouring waves.
+//
+// Storage (round 3): the device arrays are BLOCK-major - element (cell, block b, component k) of a K-component field lives
+// at ((b * K + k) * 512 + cell): the 27 populations of a block are one contiguous 54-KiB piece. The reference's arrays are
+// population-major, [8,8,8,n_blocks,K] (src/blocks.jl:118-150): 27 + 27 concurrent streams n_blocks x 2 KiB apart, and at
+// some distances (which depend on nothing but n_blocks) they load MI355X's memory system unevenly - 5-30 % of the step
+// (profiles/r03_stride_*). With block-major storage there is no such distance; the ABI translates (ludwig_hip.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -36,10 +42,8 @@ struct SCParams {
     const float *wall_dist;
     const int32_t *meta;      // [n_blocks][NBR_STRIDE]
     const int32_t *items;     // work list, one entry per wave: (block << 3) | z, or -1
-    int64_t sk;               // population stride in elements = 512 * n_blocks
     // parent level (coarse -> fine interface), unused on level 1
     const float *pf_new, *pf_old, *prho_new, *prho_old, *pvel_new, *pvel_old;
-    int64_t psk;
     float tau, tau_parent, c_wale, nu_bg, u_inlet, inlet_turbulence, temporal_weight;
     int32_t is_level_1, is_symmetric, nx_g, ny_g, nz_g;
     int32_t wall_model, seed, use_temporal, sponge_blend;
@@ -163,34 +167,59 @@ __device__ LW_WALL_INLINE float wall_model_force_mag(float dist_wall, float tau_
 }
 
 // ---- addressing helpers -------------------------------------------------------------------------------------
-// Every access is `wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane byte offset`, which gfx950 encodes as
-// global_load/store_dword v, v_off, s[base:base+1] - no 64-bit vector address arithmetic. The byte offset of a
-// cell inside one population is (block * 512 + cell) * 4 < 2^32 (checked at level creation).
-__device__ __forceinline__ float ld_f32(const float *base, uint32_t byte_off)
+// Block-major storage: byte offset of (cell, block b, component k) of a K-component float field = b * K * 2048 + k * 2048 + cell * 4.
+// The wave's own block is wave-uniform, so its accesses are `SGPR base + 32-bit per-lane byte offset`
+// (global_load/store_dword v, v_off, s[base:base+1]); only the populations pulled across a y face choose between two blocks per
+// lane. NARROW (levels below 77 672 blocks = 4 GiB of f): that choice is a 32-bit byte offset from the array base too;
+// WIDE: a 64-bit per-lane address (v_mad_u64_u32). Same loads, same values.
+constexpr uint32_t F_BLOCK_BYTES = Q * CELLS * 4, V_BLOCK_BYTES = 3 * CELLS * 4, S_BLOCK_BYTES = CELLS * 4;
+constexpr uint32_t COMP_BYTES = CELLS * 4;
+
+template <bool WIDE>
+__device__ __forceinline__ const float *cell_ptr(const float *base, int blk, uint32_t block_bytes, uint32_t inner)
+{
+    if constexpr (WIDE) return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (uint64_t)(uint32_t)blk * block_bytes + inner);
+    else return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (uint32_t)((uint32_t)blk * block_bytes + inner));
+}
+template <bool WIDE>
+__device__ __forceinline__ float ld_f32(const float *base, int blk, uint32_t block_bytes, uint32_t inner)
 {
 #ifdef LW_NT_LOADS
-    return __builtin_nontemporal_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off));
+    return __builtin_nontemporal_load(cell_ptr<WIDE>(base, blk, block_bytes, inner));
 #else
-    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+    return *cell_ptr<WIDE>(base, blk, block_bytes, inner);
 #endif
 }
 // load of a line that has exactly ONE reader in the launch (non-temporal: do not keep it in L2 / Infinity Cache)
-__device__ __forceinline__ float ld_f32_once(const float *base, uint32_t byte_off)
+template <bool WIDE>
+__device__ __forceinline__ float ld_f32_once(const float *base, int blk, uint32_t block_bytes, uint32_t inner)
 {
 #ifdef LW_NT_SINGLE_READER
-    return __builtin_nontemporal_load(reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off));
+    return __builtin_nontemporal_load(cell_ptr<WIDE>(base, blk, block_bytes, inner));
 #else
-    return ld_f32(base, byte_off);
+    return ld_f32<WIDE>(base, blk, block_bytes, inner);
 #endif
 }
-__device__ __forceinline__ void st_f32(float *base, uint32_t byte_off, float v)
+// the wave's own block (wave-uniform id): uniform 64-bit base, 32-bit per-lane offset, at any level size
+__device__ __forceinline__ float ld_own(const float *base, int blk, uint32_t block_bytes, uint32_t inner)
 {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (uint64_t)(uint32_t)blk * block_bytes + inner);
+}
+// stores go to the wave's own block only: uniform 64-bit base, 32-bit per-lane offset, at any level size
+__device__ __forceinline__ void st_f32(float *base, int blk, uint32_t block_bytes, uint32_t inner, float v)
+{
+    float *q = reinterpret_cast<float *>(reinterpret_cast<char *>(base) + (uint64_t)(uint32_t)blk * block_bytes + inner);
 #ifdef LW_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off));
+    __builtin_nontemporal_store(v, q);
 #else
-    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+    *q = v;
 #endif
 }
+// the wave's own cell: block (wave-uniform), plane and lane
+struct Own {
+    int b;            // block
+    uint32_t cell4;   // (x + 8 y + 64 z) * 4
+};
 
 // The 27 neighbour block ids of the wave's block, held in SGPRs, regrouped by source z-layer:
 // id[g][j] for g = 0 (cz=+1: source plane z-1), 1 (cz=0), 2 (cz=-1: source plane z+1), j = (ox+1) + 3(oy+1).
@@ -250,46 +279,11 @@ __device__ __forceinline__ int source_block(const NeighbourIds &n, const LanePos
     else if constexpr (cy != 0) sel = yo ? cY : c00;
     return sel;
 }
-// byte offset of the pulled cell inside its source block
-template <int K>
-__device__ __forceinline__ uint32_t source_cell_bytes(const NeighbourIds &n, const LanePos &l)
-{
-    constexpr int cx = CX(K), cy = CY(K), g = 1 - CZ(K);
-    return (uint32_t)((((l.x - cx) & 7) + 8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(n.zs[g] * 256);
-}
-
-// previous-step velocity of the face neighbour (dx,dy,dz), reference src/physics_utils.jl:45-70
-template <int DX, int DY, int DZ, bool GENERAL>
-__device__ __forceinline__ void velocity_neighbor(const SCParams &p, const NeighbourIds &n, const LanePos &l, int b, int z,
-                                                  uint32_t own_bytes, float &u1, float &u2, float &u3)
-{
-    constexpr int g = 1 + DZ;   // layer that holds the neighbour when it lies outside the block in z
-    bool out;
-    int nbid;
-    if constexpr (DX != 0) { out = DX == 1 ? l.x7 : l.x0; nbid = n.id[1][4 + DX]; }
-    else if constexpr (DY != 0) { out = DY == 1 ? l.y7 : l.y0; nbid = n.id[1][4 + 3 * DY]; }
-    else { out = DZ == 1 ? (z == 7) : (z == 0); nbid = DZ == 1 ? n.id[2][4] : n.id[0][4]; }
-    (void)g;
-    const int blk = out ? nbid : b;
-    uint32_t off = (uint32_t)blk * (CELLS * 4) +
-                   (uint32_t)((((l.x + DX) & 7) + 8 * ((l.y + DY) & 7) + 64 * ((z + DZ) & 7)) * 4);
-    if constexpr (GENERAL) {
-        if (blk < 0) off = own_bytes;   // missing neighbour block -> own value
-    }
-#ifdef LW_DIAG_NO_VEL_GATHER   // timing-only diagnostic build: results are wrong
-    u1 = __int_as_float(off); u2 = u1 * 2.0f; u3 = u1 * 3.0f;
-#else
-    u1 = ld_f32(p.vel_in, off);
-    u2 = ld_f32(p.vel_in + p.sk, off);
-    u3 = ld_f32(p.vel_in + 2 * p.sk, off);
-#endif
-}
-
 // Everything after the loads: moments, obstacle bounce, sponge, wall model, WALE, regularized collision, stores.
 // reference src/physics_kernels.jl:144-354. fs = the 27 pulled populations, u?_? = previous-step velocity of the six
 // face neighbours. Shared by the per-wave kernel and the x-run kernel.
 template <bool POST, bool WALL>
-__device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, const uint32_t own_bytes, float (&fs)[Q],
+__device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, const Own own, float (&fs)[Q],
                                             const float ux_E, const float uy_E, const float uz_E, const float ux_W, const float uy_W, const float uz_W,
                                             const float ux_N, const float uy_N, const float uz_N, const float ux_S, const float uy_S, const float uz_S,
                                             const float ux_T, const float uy_T, const float uz_T, const float ux_B, const float uy_B, const float uz_B)
@@ -297,13 +291,13 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
 #ifdef LW_DIAG_NO_MATH   // timing-only diagnostic build: same loads and stores, no collision arithmetic; results are wrong
     {
         float acc = ux_E + uy_E + uz_E + ux_W + uy_W + uz_W + ux_N + uy_N + uz_N + ux_S + uy_S + uz_S + ux_T + uy_T + uz_T + ux_B + uy_B + uz_B;
-        st_f32(p.vel_out, own_bytes, acc);
-        st_f32(p.vel_out + p.sk, own_bytes, fs[1]);
-        st_f32(p.vel_out + 2 * p.sk, own_bytes, fs[2]);
-        st_f32(p.rho, own_bytes, fs[0]);
+        st_f32(p.vel_out, own.b, V_BLOCK_BYTES, own.cell4, acc);
+        st_f32(p.vel_out, own.b, V_BLOCK_BYTES, COMP_BYTES + own.cell4, fs[1]);
+        st_f32(p.vel_out, own.b, V_BLOCK_BYTES, 2 * COMP_BYTES + own.cell4, fs[2]);
+        st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, fs[0]);
         static_for<0, Q>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
-            st_f32(p.f_out + p.sk * k, own_bytes, fs[k]);
+            st_f32(p.f_out, own.b, F_BLOCK_BYTES, k * COMP_BYTES + own.cell4, fs[k]);
         });
         return;
     }
@@ -326,17 +320,17 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     const bool store_post = (flags & FLAG_STORE_POST) != 0;
     // ---- obstacle cell: full-way bounce-back of the pulled set, reference :154-166 ----
     bool is_obs = false;
-    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own_bytes >> 2] != 0;
+    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[(size_t)own.b * CELLS + (own.cell4 >> 2)] != 0;
     if (is_obs) {
-        st_f32(p.vel_out, own_bytes, 0.0f);
-        st_f32(p.vel_out + p.sk, own_bytes, 0.0f);
-        st_f32(p.vel_out + 2 * p.sk, own_bytes, 0.0f);
-        if (p.store_rho) st_f32(p.rho, own_bytes, 1.0f);
+        st_f32(p.vel_out, own.b, V_BLOCK_BYTES, own.cell4, 0.0f);
+        st_f32(p.vel_out, own.b, V_BLOCK_BYTES, COMP_BYTES + own.cell4, 0.0f);
+        st_f32(p.vel_out, own.b, V_BLOCK_BYTES, 2 * COMP_BYTES + own.cell4, 0.0f);
+        if (p.store_rho) st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, 1.0f);
         static_for<0, Q>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
             const float f_coll = fs[OPP(k)];
-            st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
-            if constexpr (POST) { if (store_post) st_f32(p.f_post + p.sk * k, own_bytes, f_coll); }
+            st_f32(p.f_out, own.b, F_BLOCK_BYTES, k * COMP_BYTES + own.cell4, f_coll);
+            if constexpr (POST) { if (store_post) st_f32(p.f_post, own.b, F_BLOCK_BYTES, k * COMP_BYTES + own.cell4, f_coll); }
         });
         return;
     }
@@ -348,7 +342,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
 
     // ---- sponge, reference :181-199 ----
     if (flags & FLAG_HAS_SPONGE) {
-        const float sp = ld_f32(p.sponge, own_bytes);
+        const float sp = ld_own(p.sponge, own.b, S_BLOCK_BYTES, own.cell4);
         if (sp > 0.0f) {
             const float rho_target = 1.0f, ux_target = p.u_inlet;
             rho = rho * (1.0f - sp) + rho_target * sp;
@@ -372,7 +366,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     if constexpr (WALL) {
         if (flags & FLAG_HAS_NEAR_WALL) {
             const float u_mag = sqrtf(ux * ux + uy * uy + uz * uz);
-            const float force_mag = wall_model_force_mag(ld_f32(p.wall_dist, own_bytes), p.tau, rho, u_mag);
+            const float force_mag = wall_model_force_mag(ld_own(p.wall_dist, own.b, S_BLOCK_BYTES, own.cell4), p.tau, rho, u_mag);
             if (force_mag >= 0.0f) {
                 Fx = -force_mag * ux / u_mag;
                 Fy = -force_mag * uy / u_mag;
@@ -385,10 +379,10 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     }
     const float usq_eq = ux_eq * ux_eq + uy_eq * uy_eq + uz_eq * uz_eq;
 
-    st_f32(p.vel_out, own_bytes, ux);
-    st_f32(p.vel_out + p.sk, own_bytes, uy);
-    st_f32(p.vel_out + 2 * p.sk, own_bytes, uz);
-    if (p.store_rho) st_f32(p.rho, own_bytes, rho);
+    st_f32(p.vel_out, own.b, V_BLOCK_BYTES, own.cell4, ux);
+    st_f32(p.vel_out, own.b, V_BLOCK_BYTES, COMP_BYTES + own.cell4, uy);
+    st_f32(p.vel_out, own.b, V_BLOCK_BYTES, 2 * COMP_BYTES + own.cell4, uz);
+    if (p.store_rho) st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, rho);
 
     // ---- WALE eddy viscosity from the previous step's velocity, reference :251-300 ----
     const float g11 = 0.5f * (ux_E - ux_W), g12 = 0.5f * (ux_N - ux_S), g13 = 0.5f * (ux_T - ux_B);
@@ -466,37 +460,37 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
                                                      (cz_f - uz + 3.0f * cu * cz_f) * Fz);
             f_coll = f_coll + one_m_half_omega * force_term;
         }
-        if constexpr (POST) { if (store_post) st_f32(p.f_post + p.sk * k, own_bytes, f_coll); }
-        st_f32(p.f_out + p.sk * k, own_bytes, f_coll);
+        if constexpr (POST) { if (store_post) st_f32(p.f_post, own.b, F_BLOCK_BYTES, k * COMP_BYTES + own.cell4, f_coll); }
+        st_f32(p.f_out, own.b, F_BLOCK_BYTES, k * COMP_BYTES + own.cell4, f_coll);
     });
 }
 
 // The density finish_cell would have stored for this cell, and nothing else: the same sums in the same order (reference
 // src/physics_kernels.jl:144-148, :154-158 obstacle, :172 clamp, :181-186 sponge). Used to produce `rho` on demand after a
 // step that skipped the store.
-__device__ __forceinline__ void finish_rho_only(const SCParams &p, const int flags, const uint32_t own_bytes, const float (&fs)[Q])
+__device__ __forceinline__ void finish_rho_only(const SCParams &p, const int flags, const Own own, const float (&fs)[Q])
 {
     float rho = 0.0f;
     static_for<0, Q>([&](auto kc) { rho += fs[decltype(kc)::value]; });
     bool is_obs = false;
-    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[own_bytes >> 2] != 0;
-    if (is_obs) { st_f32(p.rho, own_bytes, 1.0f); return; }
+    if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[(size_t)own.b * CELLS + (own.cell4 >> 2)] != 0;
+    if (is_obs) { st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, 1.0f); return; }
     rho = jl_max(rho, 0.01f);
     if (flags & FLAG_HAS_SPONGE) {
-        const float sp = ld_f32(p.sponge, own_bytes);
+        const float sp = ld_own(p.sponge, own.b, S_BLOCK_BYTES, own.cell4);
         if (sp > 0.0f) rho = rho * (1.0f - sp) + 1.0f * sp;
     }
-    st_f32(p.rho, own_bytes, rho);
+    st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, rho);
 }
 
 // Lanes whose source block is missing: the domain-edge chain of reference src/physics_kernels.jl:88-140 (1-based global
 // coords) decides what replaces the pulled value - inlet / outlet equilibrium, mirror of the own cell, the coarse->fine
 // interface value, or the weight. Runs after all loads were issued (the lane read a valid dummy address meanwhile).
 __device__ __forceinline__ void patch_missing_sources(const SCParams &p, const int32_t *__restrict__ meta, const NeighbourIds &nbr,
-                                                      const LanePos &l, const int b, const int z, const uint32_t own_bytes, float (&fs)[Q])
+                                                      const LanePos &l, const int z, const Own own, float (&fs)[Q])
 {
     const int gx = (meta[NBR_BX] - 1) * BS + l.x + 1, gy = (meta[NBR_BY] - 1) * BS + l.y + 1, gz = (meta[NBR_BZ] - 1) * BS + z + 1;
-    const float *iface_own = p.is_level_1 == 0 ? p.f_iface + (size_t)meta[NBR_GBI] * CELLS + ((own_bytes >> 2) - (size_t)b * CELLS) : nullptr;
+    const float *iface_own = p.is_level_1 == 0 ? p.f_iface + (size_t)meta[NBR_GBI] * CELLS + (own.cell4 >> 2) : nullptr;
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int cx = CX(k), cy = CY(k), cz = CZ(k);
@@ -518,11 +512,11 @@ __device__ __forceinline__ void patch_missing_sources(const SCParams &p, const i
                     const float cu_out = (float)cx * p.u_inlet;
                     val = WEIGHT(k) * (1.0f + 3.0f * cu_out + 4.5f * cu_out * cu_out - 1.5f * p.u_inlet * p.u_inlet);
                 } else if (is_y_min && p.is_symmetric == 1) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                    val = ld_own(p.f_in, own.b, F_BLOCK_BYTES, MIRROR_Y(k) * COMP_BYTES + own.cell4);
                 } else if (is_y_min || is_y_max) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Y(k), own_bytes);
+                    val = ld_own(p.f_in, own.b, F_BLOCK_BYTES, MIRROR_Y(k) * COMP_BYTES + own.cell4);
                 } else if (is_z_min || is_z_max) {
-                    val = ld_f32(p.f_in + p.sk * MIRROR_Z(k), own_bytes);
+                    val = ld_own(p.f_in, own.b, F_BLOCK_BYTES, MIRROR_Z(k) * COMP_BYTES + own.cell4);
                 } else if (p.is_level_1 == 0) {
                     // value computed by k_interface_links for exactly this (cell, k) link (same function, same inputs)
                     val = iface_own[(size_t)k * p.n_iface_blocks * CELLS];
@@ -535,58 +529,9 @@ __device__ __forceinline__ void patch_missing_sources(const SCParams &p, const i
     });
 }
 
+// ---- the stream-collide kernel --------------------------------------------------------------------------------
 // GENERAL: blocks with a missing neighbour (domain edge / refinement interface); POST: also store f_post_collision
-// (level has Bouzidi cells); WALL: wall model active.
-#ifndef LW_WAVES_PER_EU
-#define LW_WAVES_ATTR
-#else
-#define LW_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(LW_WAVES_PER_EU, LW_WAVES_PER_EU)))
-#endif
-template <bool GENERAL, bool POST, bool WALL>
-__global__ __launch_bounds__(256) LW_WAVES_ATTR void k_stream_collide(const SCParams p)
-{
-    // one work item per WAVE: (block << 3) | z. Which waves share a workgroup / an XCD is the host's choice (order.py).
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int item = p.items[blockIdx.x * 4 + wave];
-    if (item < 0) return;                                   // padding slot of an XCD-aligned launch order
-    const int b = item >> 3;
-    const int z = item & 7;                                 // wave-uniform z-plane, 0-based
-    const int lane = threadIdx.x & 63;
-    LanePos l;
-    l.x = lane & 7; l.y = lane >> 3;
-    l.x0 = l.x == 0; l.x7 = l.x == 7; l.y0 = l.y == 0; l.y7 = l.y == 7;
-    const int32_t *__restrict__ meta = p.meta + (size_t)b * NBR_STRIDE;
-    const int flags = meta[NBR_FLAGS];
-    const NeighbourIds nbr = load_neighbour_ids(meta, z);
-    const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
-
-    // ---- pull-stream, reference src/physics_kernels.jl:62-149 ----
-    // All 27 loads are issued first, branch-free (a lane whose source block is missing reads the same cell of its own block
-    // instead: in bounds, value unused), so they are in flight together; only then the missing-source lanes are patched.
-    float fs[Q];
-    static_for<0, Q>([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        const int sel = source_block<k>(nbr, l);
-        const int safe = GENERAL ? (sel >= 0 ? sel : b) : sel;
-        const uint32_t off = (uint32_t)safe * (CELLS * 4) + source_cell_bytes<k>(nbr, l);
-        fs[k] = ld_f32(p.f_in + p.sk * k, off);
-    });
-    if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, b, z, own_bytes, fs);
-    // previous-step velocity of the 6 face neighbours (WALE stencil) - issued with the pulls so that all loads of the
-    // wave are in flight together; reference src/physics_utils.jl:72-83
-    float ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S, ux_T, uy_T, uz_T, ux_B, uy_B, uz_B;
-    velocity_neighbor<1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_E, uy_E, uz_E);
-    velocity_neighbor<-1, 0, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_W, uy_W, uz_W);
-    velocity_neighbor<0, 1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_N, uy_N, uz_N);
-    velocity_neighbor<0, -1, 0, GENERAL>(p, nbr, l, b, z, own_bytes, ux_S, uy_S, uz_S);
-    velocity_neighbor<0, 0, 1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_T, uy_T, uz_T);
-    velocity_neighbor<0, 0, -1, GENERAL>(p, nbr, l, b, z, own_bytes, ux_B, uy_B, uz_B);
-
-    finish_cell<POST, WALL>(p, flags, own_bytes, fs, ux_E, uy_E, uz_E, ux_W, uy_W, uz_W, ux_N, uy_N, uz_N, ux_S, uy_S, uz_S,
-                            ux_T, uy_T, uz_T, ux_B, uy_B, uz_B);
-}
-
-// ---- x-run variant of the all-neighbours kernel ------------------------------------------------------------
+// (level has Bouzidi cells); WALL: wall model active; RHO_ONLY: reproduce an elided rho; WIDE: 64-bit per-lane addresses.
 // Workgroup = the SAME z-plane of NW x-consecutive blocks (host guarantees: items 0..NW-1 of the group are valid,
 // share z, item i+1 is the +x neighbour of item i, all blocks have their 26 neighbours). Every global access is an
 // aligned 256-B plane row set (x unshifted; the y / z shift only changes the row / plane, i.e. stays 16-B aligned);
@@ -612,8 +557,11 @@ constexpr int ITEM_LINK_W = 1 << 30;   // wave - 1 of this workgroup holds the -
 constexpr int ITEM_LINK_E = 1 << 29;   // wave + 1 holds the +x neighbour block, same plane
 constexpr int ITEM_ID_MASK = (1 << 29) - 1;
 
-template <int NW, bool GENERAL, bool POST, bool WALL, bool RHO_ONLY = false>
-__global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams p)
+#ifndef LW_MIN_WAVES
+#define LW_MIN_WAVES 5      // waves per SIMD the register allocator must leave room for (96 VGPRs)
+#endif
+template <int NW, bool GENERAL, bool POST, bool WALL, bool RHO_ONLY = false, bool WIDE = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((WIDE && GENERAL) ? LW_MIN_WAVES - 1 : LW_MIN_WAVES))) void k_stream_collide_xrun(const SCParams p)
 {
     __shared__ float xch[NW][24][8];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -634,7 +582,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
     const int flags = meta[NBR_FLAGS];
 #endif
     const NeighbourIds nbr = load_neighbour_ids(meta, z);
-    const uint32_t own_bytes = (uint32_t)b * (CELLS * 4) + (uint32_t)((l.x + 8 * l.y + 64 * z) * 4);
+    const Own own{b, (uint32_t)((l.x + 8 * l.y + 64 * z) * 4)};
     // wave-uniform: a run may be shorter than the workgroup (several short runs, or single blocks, share one)
     const bool first = !active || (raw & ITEM_LINK_W) == 0, last = !active || (raw & ITEM_LINK_E) == 0;
     float fs[Q];
@@ -653,12 +601,11 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         const int c00 = nbr.id[g][4], cY = nbr.id[g][4 - 3 * cy];
         int sel = cy != 0 ? (yo ? cY : c00) : c00;
         if constexpr (GENERAL) sel = sel >= 0 ? sel : b;      // missing block: in-bounds dummy, patched after the exchange
-        const uint32_t rowz = (uint32_t)((8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(nbr.zs[g] * 256);
-        const float *fk = p.f_in + p.sk * k;
-        // populations with cy = 0: the two lines of this plane are read by this wave only (the x neighbours get their
-        // column through LDS, nobody shifts rows) -> single reader
-        if constexpr (cy == 0) fs[k] = ld_f32_once(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
-        else fs[k] = ld_f32(fk, (uint32_t)sel * (CELLS * 4) + rowz + (uint32_t)(l.x * 4));
+        const uint32_t rowz = (uint32_t)(k * COMP_BYTES) + (uint32_t)((8 * ((l.y - cy) & 7)) * 4) + (uint32_t)(nbr.zs[g] * 256);
+        // populations with cy = 0: the block is wave-uniform (SGPR base) and the two lines of this plane are read by this wave
+        // only (the x neighbours get their column through LDS, nobody shifts rows) -> single reader
+        if constexpr (cy == 0) fs[k] = ld_f32_once<true>(p.f_in, sel, F_BLOCK_BYTES, rowz + (uint32_t)(l.x * 4));
+        else fs[k] = ld_f32<WIDE>(p.f_in, sel, F_BLOCK_BYTES, rowz + (uint32_t)(l.x * 4));
         halo[k] = 0.0f;
         if constexpr (cx != 0) {
 #ifdef LW_DIAG_NO_OUTER   // timing-only
@@ -670,48 +617,47 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
                 int selx = cy != 0 ? (yo ? cXY : cX) : cX;
                 if constexpr (GENERAL) selx = selx >= 0 ? selx : b;
                 if (cx == 1 ? l.x0 : l.x7)
-                    halo[k] = ld_f32(fk, (uint32_t)selx * (CELLS * 4) + rowz + (uint32_t)((cx == 1 ? 7 : 0) * 4));
+                    halo[k] = ld_f32<(cy == 0) || WIDE>(p.f_in, selx, F_BLOCK_BYTES, rowz + (uint32_t)((cx == 1 ? 7 : 0) * 4));
             }
         }
     });
     // previous-step velocity: centre plane, planes z+-1 (aligned), y-face rows and outer x-face columns (masked)
     if constexpr (!RHO_ONLY) {
-        const int bT = z == 7 ? nbr.id[2][4] : b, bB = z == 0 ? nbr.id[0][4] : b;
+        int bT = z == 7 ? nbr.id[2][4] : b, bB = z == 0 ? nbr.id[0][4] : b;      // wave-uniform
         const uint32_t xy = (uint32_t)((l.x + 8 * l.y) * 4);
-        uint32_t offT = (uint32_t)bT * (CELLS * 4) + xy + (uint32_t)(((z + 1) & 7) * 256);
-        uint32_t offB = (uint32_t)bB * (CELLS * 4) + xy + (uint32_t)(((z - 1) & 7) * 256);
+        uint32_t inT = xy + (uint32_t)(((z + 1) & 7) * 256), inB = xy + (uint32_t)(((z - 1) & 7) * 256);
         // lanes y==0 fetch row 7 of the -y neighbour, lanes y==7 row 0 of the +y neighbour (one masked load per component)
-        const int by_ = l.y0 ? nbr.id[1][4 - 3] : nbr.id[1][4 + 3];
-        uint32_t offY = (uint32_t)by_ * (CELLS * 4) + (uint32_t)((l.x + 8 * (l.y0 ? 7 : 0) + 64 * z) * 4);
-        uint32_t offXlo = (uint32_t)nbr.id[1][4 - 1] * (CELLS * 4) + (uint32_t)((7 + 8 * l.y + 64 * z) * 4);
-        uint32_t offXhi = (uint32_t)nbr.id[1][4 + 1] * (CELLS * 4) + (uint32_t)((0 + 8 * l.y + 64 * z) * 4);
+        int by_ = l.y0 ? nbr.id[1][4 - 3] : nbr.id[1][4 + 3];
+        uint32_t inY = (uint32_t)((l.x + 8 * (l.y0 ? 7 : 0) + 64 * z) * 4);
+        int bXlo = nbr.id[1][4 - 1], bXhi = nbr.id[1][4 + 1];                    // wave-uniform
+        uint32_t inXlo = (uint32_t)((7 + 8 * l.y + 64 * z) * 4), inXhi = (uint32_t)((0 + 8 * l.y + 64 * z) * 4);
         if constexpr (GENERAL) {      // missing neighbour block -> the cell's own velocity (reference src/physics_utils.jl:45-70)
-            if (bT < 0) offT = own_bytes;
-            if (bB < 0) offB = own_bytes;
-            if (by_ < 0) offY = own_bytes;
-            if (nbr.id[1][4 - 1] < 0) offXlo = own_bytes;
-            if (nbr.id[1][4 + 1] < 0) offXhi = own_bytes;
+            if (bT < 0) { bT = b; inT = own.cell4; }
+            if (bB < 0) { bB = b; inB = own.cell4; }
+            if (by_ < 0) { by_ = b; inY = own.cell4; }
+            if (bXlo < 0) { bXlo = b; inXlo = own.cell4; }
+            if (bXhi < 0) { bXhi = b; inXhi = own.cell4; }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float *vc = p.vel_in + p.sk * c;
+            const uint32_t cb = (uint32_t)c * COMP_BYTES;
 #if defined(LW_DIAG_NO_VEL)   // timing-only
-            uc[c] = __int_as_float(own_bytes + c); uT[c] = uc[c]; uB[c] = uc[c]; uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
-            (void)vc; (void)offT; (void)offB; (void)offY; (void)offXlo; (void)offXhi;
+            uc[c] = __int_as_float(own.cell4 + c); uT[c] = uc[c]; uB[c] = uc[c]; uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
+            (void)cb; (void)inT; (void)inB; (void)inY; (void)inXlo; (void)inXhi;
 #elif defined(LW_DIAG_NO_VEL_TB)
-            uc[c] = ld_f32(vc, own_bytes); uT[c] = uc[c]; uB[c] = uc[c];
+            uc[c] = ld_own(p.vel_in, b, V_BLOCK_BYTES, cb + own.cell4); uT[c] = uc[c]; uB[c] = uc[c];
             uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
-            if (l.y0 || l.y7) uy_edge[c] = ld_f32(vc, offY);
-            if (first) { if (l.x0) ux_edge_lo[c] = ld_f32(vc, offXlo); }
-            if (last) { if (l.x7) ux_edge_hi[c] = ld_f32(vc, offXhi); }
+            if (l.y0 || l.y7) uy_edge[c] = ld_f32<WIDE>(p.vel_in, by_, V_BLOCK_BYTES, cb + inY);
+            if (first) { if (l.x0) ux_edge_lo[c] = ld_own(p.vel_in, bXlo, V_BLOCK_BYTES, cb + inXlo); }
+            if (last) { if (l.x7) ux_edge_hi[c] = ld_own(p.vel_in, bXhi, V_BLOCK_BYTES, cb + inXhi); }
 #else
-            uc[c] = ld_f32(vc, own_bytes);
-            uT[c] = ld_f32(vc, offT);
-            uB[c] = ld_f32(vc, offB);
+            uc[c] = ld_own(p.vel_in, b, V_BLOCK_BYTES, cb + own.cell4);
+            uT[c] = ld_own(p.vel_in, bT, V_BLOCK_BYTES, cb + inT);
+            uB[c] = ld_own(p.vel_in, bB, V_BLOCK_BYTES, cb + inB);
             uy_edge[c] = 0.0f; ux_edge_lo[c] = 0.0f; ux_edge_hi[c] = 0.0f;
-            if (l.y0 || l.y7) uy_edge[c] = ld_f32(vc, offY);
-            if (first) { if (l.x0) ux_edge_lo[c] = ld_f32(vc, offXlo); }
-            if (last) { if (l.x7) ux_edge_hi[c] = ld_f32(vc, offXhi); }
+            if (l.y0 || l.y7) uy_edge[c] = ld_f32<WIDE>(p.vel_in, by_, V_BLOCK_BYTES, cb + inY);
+            if (first) { if (l.x0) ux_edge_lo[c] = ld_own(p.vel_in, bXlo, V_BLOCK_BYTES, cb + inXlo); }
+            if (last) { if (l.x7) ux_edge_hi[c] = ld_own(p.vel_in, bXhi, V_BLOCK_BYTES, cb + inXhi); }
 #endif
         }
     }
@@ -758,8 +704,8 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         }
     });
     if constexpr (RHO_ONLY) {
-        if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, b, z, own_bytes, fs);
-        finish_rho_only(p, flags, own_bytes, fs);
+        if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, z, own, fs);
+        finish_rho_only(p, flags, own, fs);
         return;
     }
     float uE[3], uW[3], uN[3], uS[3];
@@ -776,8 +722,8 @@ __global__ __launch_bounds__(64 * NW) void k_stream_collide_xrun(const SCParams 
         uN[c] = l.y7 ? uy_edge[c] : n_in;
         uS[c] = l.y0 ? uy_edge[c] : s_in;
     }
-    if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, b, z, own_bytes, fs);
-    finish_cell<POST, WALL>(p, flags, own_bytes, fs, uE[0], uE[1], uE[2], uW[0], uW[1], uW[2], uN[0], uN[1], uN[2], uS[0], uS[1], uS[2],
+    if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, z, own, fs);
+    finish_cell<POST, WALL>(p, flags, own, fs, uE[0], uE[1], uE[2], uW[0], uW[1], uW[2], uN[0], uN[1], uN[2], uS[0], uS[1], uS[2],
                             uT[0], uT[1], uT[2], uB[0], uB[1], uB[2]);
 }
 
@@ -831,10 +777,11 @@ __global__ __launch_bounds__(256) void k_interface_sources(const SCParams p, con
         v1[0][n] = 1.0f; v1[1][n] = 0.0f; v1[2][n] = 0.0f; v1[3][n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
         v2[0][n] = 1.0f; v2[1][n] = 0.0f; v2[2][n] = 0.0f; v2[3][n] = 0.0f;
         if (cc[n] >= 0) {
-            const int c = cc[n];
-            const float vn[4] = {p.prho_new[c], p.pvel_new[c], p.pvel_new[c + p.psk], p.pvel_new[c + 2 * p.psk]};
+            const int c = cc[n];                                 // parent cell: block * 512 + cell
+            const size_t cv = (size_t)(c >> 9) * (3 * CELLS) + (c & 511);      // component 0 of the block-major velocity array
+            const float vn[4] = {p.prho_new[c], p.pvel_new[cv], p.pvel_new[cv + CELLS], p.pvel_new[cv + 2 * CELLS]};
             float vo[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (blend || blend2) { vo[0] = p.prho_old[c]; vo[1] = p.pvel_old[c]; vo[2] = p.pvel_old[c + p.psk]; vo[3] = p.pvel_old[c + 2 * p.psk]; }
+            if (blend || blend2) { vo[0] = p.prho_old[c]; vo[1] = p.pvel_old[cv]; vo[2] = p.pvel_old[cv + CELLS]; vo[3] = p.pvel_old[cv + 2 * CELLS]; }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 v1[q][n] = blend_in_time(blend, vo[q], vn[q], tw);
@@ -871,15 +818,15 @@ __global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const
     const float tw = p.temporal_weight, tw2 = a.tw2;
     const bool blend = p.use_temporal == 1 && tw < 0.99f, blend2 = TWO && p.use_temporal == 1 && tw2 < 0.99f;
     const float w_k = weight_rt(k);
-    const int64_t koff = p.psk * k;
     float fc[8], fc2[8];
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         fc[n] = w_k; fc2[n] = w_k;
         if (cc[n] >= 0) {
-            const float fn = p.pf_new[(int64_t)cc[n] + koff];
+            const size_t cf = ((size_t)(cc[n] >> 9) * Q + k) * CELLS + (cc[n] & 511);      // population k of the parent cell
+            const float fn = p.pf_new[cf];
             float fo = 0.0f;
-            if (blend || blend2) fo = p.pf_old[(int64_t)cc[n] + koff];
+            if (blend || blend2) fo = p.pf_old[cf];
             fc[n] = blend_in_time(blend, fo, fn, tw);
             if (TWO) fc2[n] = blend_in_time(blend2, fo, fn, tw2);
         }
@@ -915,7 +862,6 @@ struct BouzidiParams {
     const int32_t *cell_block;   // 0-based
     const int8_t *cell_x, *cell_y, *cell_z;   // 0-based
     const int32_t *meta;
-    int64_t sk;
     int32_t n_cells;
     float q_min;
     const int2 *links;           // compact list of the links with q > 0: (block * 512 + cell, k); nullptr = all (cell, k)
@@ -942,41 +888,43 @@ __global__ __launch_bounds__(256) void k_bouzidi(const BouzidiParams p)
         x = p.cell_x[c]; y = p.cell_y[c]; z = p.cell_z[c];
     }
     const int opp_k = 26 - k;
-    const int64_t own = (int64_t)b * CELLS + x + 8 * y + 64 * z;
-    const float q = (float)p.q_map[own + p.sk * k];
+    const int cell = x + 8 * y + 64 * z;
+    auto at = [](int blk, int kk, int c) { return ((size_t)blk * Q + kk) * CELLS + c; };      // block-major f / q map
+    const float q = (float)p.q_map[at(b, k, cell)];
     if (q > p.q_min && q <= 1.0f) {
-        const float f_k = p.f_post[own + p.sk * k];
+        const float f_k = p.f_post[at(b, k, cell)];
         if (q < 0.5f) {
             const int nx = x + (opp_k % 3 - 1), ny = y + ((opp_k / 3) % 3 - 1), nz = z + (opp_k / 9 - 1);
             float f_ff = f_k;
             if (nx >= 0 && nx < BS && ny >= 0 && ny < BS && nz >= 0 && nz < BS) {
-                f_ff = p.f_post[(int64_t)b * CELLS + nx + 8 * ny + 64 * nz + p.sk * k];
+                f_ff = p.f_post[at(b, k, nx + 8 * ny + 64 * nz)];
             } else {
                 const int ox = nx < 0 ? -1 : (nx >= BS ? 1 : 0);
                 const int oy = ny < 0 ? -1 : (ny >= BS ? 1 : 0);
                 const int oz = nz < 0 ? -1 : (nz >= BS ? 1 : 0);
                 const int nbb = p.meta[(int64_t)b * NBR_STRIDE + DIR(ox, oy, oz)];
-                if (nbb >= 0) f_ff = p.f_post[(int64_t)nbb * CELLS + (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7) + p.sk * k];
+                if (nbb >= 0) f_ff = p.f_post[at(nbb, k, (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7))];
             }
             const float coeff1 = 2.0f * q;
-            p.f_out[own + p.sk * opp_k] = coeff1 * f_k + (1.0f - coeff1) * f_ff;
+            p.f_out[at(b, opp_k, cell)] = coeff1 * f_k + (1.0f - coeff1) * f_ff;
         } else {
-            const float f_opp_post = p.f_post[own + p.sk * opp_k];
+            const float f_opp_post = p.f_post[at(b, opp_k, cell)];
             const float inv_2q = 1.0f / (2.0f * q);
             const float coeff2 = (2.0f * q - 1.0f) * inv_2q;
-            p.f_out[own + p.sk * opp_k] = inv_2q * f_k + coeff2 * f_opp_post;
+            p.f_out[at(b, opp_k, cell)] = inv_2q * f_k + coeff2 * f_opp_post;
         }
     }
 }
 
 // ---- init_eq!, reference src/main.jl:109-124 ----
-__global__ void k_fill_weights(float *f, int64_t sk)
+__global__ void k_fill_weights(float *f, int64_t n_cells)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sk) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // cell index: block * 512 + cell
+    if (i >= n_cells) return;
+    float *q = f + (i >> 9) * (int64_t)(Q * CELLS) + (i & 511);
     static_for<0, Q>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        f[i + sk * k] = WEIGHT(k);
+        q[k * CELLS] = WEIGHT(k);
     });
 }
 __global__ void k_fill(float *a, int64_t n, float v)
@@ -990,7 +938,6 @@ struct SurfaceParams {
     const float *rho, *vel;
     const uint8_t *obstacle;
     const int32_t *block_pointer;    // [gdx,gdy,gdz] 1-based, 0 = absent
-    int64_t sk;
     int32_t gdx, gdy, gdz, n_tri, radius;
     float dx, tau, off_x, off_y, off_z, pressure_scale, stress_scale;
     const float *centers, *normals;  // [n_tri * 3]
@@ -1026,7 +973,8 @@ __global__ __launch_bounds__(128) void k_map_stresses(const SurfaceParams s)
                     if (d2 < best_d) {
                         best_d = d2;
                         best_rho = s.rho[c];
-                        ux = s.vel[c]; uy = s.vel[c + s.sk]; uz = s.vel[c + 2 * s.sk];
+                        const int64_t cv = (c >> 9) * (int64_t)(3 * CELLS) + (c & 511);      // block-major velocity
+                        ux = s.vel[cv]; uy = s.vel[cv + CELLS]; uz = s.vel[cv + 2 * CELLS];
                         best_wd = sqrtf(d2) / s.dx;
                         found = true;
                     }
@@ -1072,41 +1020,64 @@ __global__ __launch_bounds__(256) void k_rho_min(const float *__restrict__ rho, 
     }
 }
 
-// ---- internal block order (ludwig_hip.hip "block order"): the caller's arrays keep the reference's block order, the device
-// arrays hold the blocks in the library's own order; ref2int[b_reference] = b_internal ----
+// ---- internal storage (ludwig_hip.hip "block order", "block-major"): the caller's arrays keep the reference's layout,
+// [8,8,8,n_blocks,K] with the reference's block order; the device arrays hold the blocks in the library's own order, block-major.
+// ref2int[b_reference] = b_internal (nullptr = same order) ----
 // element offset in the reference layout (cell + 512 b + 512 n_blocks k) -> the same element in the device array
-// (sk_ref = 512 n_blocks: the caller's population stride; sk: the device array's)
-__device__ __forceinline__ int64_t to_internal_offset(int64_t off, const int32_t *__restrict__ ref2int, int64_t sk_ref, int64_t sk)
+__device__ __forceinline__ int64_t to_internal_offset(int64_t off, const int32_t *__restrict__ ref2int, int64_t n_cells, int K)
 {
-    if (!ref2int && sk == sk_ref) return off;
-    const int64_t k = off / sk_ref, r = off - k * sk_ref;
-    return k * sk + (ref2int ? (int64_t)ref2int[r >> 9] : (r >> 9)) * CELLS + (r & 511);
+    const int64_t k = off / n_cells, r = off - k * n_cells;
+    const int64_t blk = ref2int ? (int64_t)ref2int[r >> 9] : (r >> 9);
+    return (blk * K + k) * CELLS + (r & 511);
 }
+// one component k of a K-component field: src / dst = that component in the reference layout, n = 512 n_blocks elements
 template <class T>
-__global__ __launch_bounds__(256) void k_blocks_to_internal(T *__restrict__ dst, const T *__restrict__ src, const int32_t *__restrict__ ref2int, int64_t n)
+__global__ __launch_bounds__(256) void k_component_to_internal(T *__restrict__ dev, const T *__restrict__ src, const int32_t *__restrict__ ref2int, int64_t n, int K, int k)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[(int64_t)ref2int[i >> 9] * CELLS + (i & 511)] = src[i];
+    if (i < n) dev[((ref2int ? (int64_t)ref2int[i >> 9] : (i >> 9)) * K + k) * CELLS + (i & 511)] = src[i];
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_blocks_to_reference(T *__restrict__ dst, const T *__restrict__ src, const int32_t *__restrict__ ref2int, int64_t n)
+__global__ __launch_bounds__(256) void k_component_to_reference(T *__restrict__ dst, const T *__restrict__ dev, const int32_t *__restrict__ ref2int, int64_t n, int K, int k)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[(int64_t)ref2int[i >> 9] * CELLS + (i & 511)];
+    if (i < n) dst[i] = dev[((ref2int ? (int64_t)ref2int[i >> 9] : (i >> 9)) * K + k) * CELLS + (i & 511)];
 }
 
 // ---- halo pack / unpack: index holds element offsets in the REFERENCE layout ----
 __global__ void k_gather(const float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, float *__restrict__ dst,
-                         const int32_t *__restrict__ ref2int, int64_t sk_ref, int64_t sk)
+                         const int32_t *__restrict__ ref2int, int64_t n_cells, int K)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = field[to_internal_offset(index[i], ref2int, sk_ref, sk)];
+    if (i < n) dst[i] = field[to_internal_offset(index[i], ref2int, n_cells, K)];
 }
 __global__ void k_scatter(float *__restrict__ field, const int64_t *__restrict__ index, int64_t n, const float *__restrict__ src,
-                          const int32_t *__restrict__ ref2int, int64_t sk_ref, int64_t sk)
+                          const int32_t *__restrict__ ref2int, int64_t n_cells, int K)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) field[to_internal_offset(index[i], ref2int, sk_ref, sk)] = src[i];
+    if (i < n) field[to_internal_offset(index[i], ref2int, n_cells, K)] = src[i];
+}
+
+// ---- structured halo pack / unpack (ludwig_halo_plan_*): the elements of a message grouped into OCTETS - aligned groups of 8
+// consecutive floats of the device array = one 32-B sector - with a mask of the members that travel. desc = (octet index in the
+// field, position of the octet's first member in the message, mask, unused). Eight threads share a descriptor: the sector is
+// read / written once, whole, and the message side is contiguous. A z face (whole 8x8 planes) and a y face (rows of 8) are full
+// octets: 16 B of descriptor per 32 B of payload, against 8 B of index per 4 B with k_gather / k_scatter. ----
+__global__ __launch_bounds__(256) void k_pack_octets(const float *__restrict__ field, const uint4 *__restrict__ desc, int64_t n_oct, float *__restrict__ msg)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, o = t >> 3;
+    const int j = (int)(t & 7);
+    if (o >= n_oct) return;
+    const uint4 d = desc[o];
+    if ((d.z >> j) & 1u) msg[(size_t)d.y + __popc(d.z & ((1u << j) - 1u))] = field[(size_t)d.x * 8 + j];
+}
+__global__ __launch_bounds__(256) void k_unpack_octets(float *__restrict__ field, const uint4 *__restrict__ desc, int64_t n_oct, const float *__restrict__ msg)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, o = t >> 3;
+    const int j = (int)(t & 7);
+    if (o >= n_oct) return;
+    const uint4 d = desc[o];
+    if ((d.z >> j) & 1u) field[(size_t)d.x * 8 + j] = msg[(size_t)d.y + __popc(d.z & ((1u << j) - 1u))];
 }
 
 }  // namespace lw

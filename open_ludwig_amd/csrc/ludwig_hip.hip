@@ -37,10 +37,8 @@ int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(LUDWIG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 0 = all-neighbours kernel, 1 = general kernel, 2 = x-run kernel
-constexpr int XRUN_MAX = 8;
-static int xrun_len() { static int v = [] { const char *e = getenv("LUDWIG_XRUN"); int n = e ? atoi(e) : 4; return n == 8 ? 8 : 4; }(); return v; }
-#define XRUN (xrun_len())               // waves per x-run workgroup: 4 (default) or 8 (LUDWIG_XRUN=8; 16 was tried: 25 % slower)
+constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 1 = blocks with a missing neighbour (GENERAL instantiation), 2 = all-neighbour blocks; 0 unused
+constexpr int XRUN = 4, XRUN_MAX = 4;       // waves per workgroup = blocks of an x-run (8 and 16 were tried in rounds 1-2: slower)
 
 }  // namespace
 
@@ -50,12 +48,15 @@ struct LudwigLevel {
     int level_id = 1, n_blocks = 0, n_owned = 0;
     float tau = 1.0f;
     int gdx = 0, gdy = 0, gdz = 0;
-    // Population stride. The caller's arrays are [8,8,8,n_blocks,K]: sk_ref = 512 * n_blocks elements between two populations
-    // (reference src/blocks.jl:118-150). The device arrays keep sk >= sk_ref elements between them (choose_stride_blocks below):
-    // 27 + 27 concurrent streams that far apart load MI355X's memory channels unevenly at some distances (5-20 % of the step,
-    // profiles/r02_population_stride_sweep.txt), and n_blocks is whatever the geometry gives. Translated at the ABI like the
-    // block order; only raw pointers see it (ludwig_level_population_stride).
-    int64_t sk = 0, sk_ref = 0;
+    // Storage. The caller's arrays are [8,8,8,n_blocks,K], population-major (reference src/blocks.jl:118-150); the device arrays are
+    // BLOCK-major: element (cell, block b, component k) at ((b * K + k) * 512 + cell) - the 27 populations of a block are one
+    // contiguous 54-KiB piece. With the reference's layout the step is 27 + 27 concurrent streams n_blocks x 2 KiB apart, and at
+    // some distances - 64.5, 65.75, 68, 76-77 ... MiB for boxes around 256^3, far denser for the small levels of a nested case -
+    // they load MI355X's memory system unevenly: 5-30 % of the step, decided by nothing but n_blocks (profiles/r03_stride_*).
+    // Block-major storage has no such distance, and the step's data movement is 5-12 % faster than at the best stride.
+    // Translated at the ABI like the block order; only raw pointers see it (ludwig_level_field_layout).
+    int64_t sk = 0;        // cells of the level = 512 * n_blocks (the reference's population stride; here only a count)
+    bool wide = false;     // 64-bit per-lane addresses: the level's f array is 4 GiB or more (>= 77 672 blocks), or LUDWIG_WIDE_ADDR
     float *f[2] = {nullptr, nullptr};      // f, f_temp
     float *vel[2] = {nullptr, nullptr};    // vel, vel_temp
     float *rho = nullptr, *f_post = nullptr, *f_old = nullptr, *rho_old = nullptr, *vel_old = nullptr;
@@ -174,6 +175,8 @@ int fill(LudwigLevel *L, float *a, int64_t n, float v)
 struct FieldDesc {
     void *ptr;
     size_t bytes;
+    int comps = 1;     // K: components per cell
+    int es = 4;        // element size in bytes
 };
 
 int ensure_rho(LudwigLevel *L);
@@ -210,28 +213,27 @@ int before_external_write(LudwigLevel *L, int field)
     return hits ? materialize_old(L) : LUDWIG_OK;
 }
 
-// bytes = size of the field in the CALLER's layout (stride sk_ref); the device array is comps x sk elements
 FieldDesc field_desc(const LudwigLevel *L, int field)
 {
-    const size_t c = (size_t)L->sk_ref;
+    const size_t c = (size_t)L->sk;
     if (L->old_alias >= 0) {          // readers of the saved state follow the alias
-        if (field == LUDWIG_F_OLD) return {L->f[L->old_alias], L->has_temporal ? c * Q * 4 : 0};
-        if (field == LUDWIG_VEL_OLD) return {L->vel[L->old_alias], L->has_temporal ? c * 3 * 4 : 0};
+        if (field == LUDWIG_F_OLD) return {L->f[L->old_alias], L->has_temporal ? c * Q * 4 : 0, Q, 4};
+        if (field == LUDWIG_VEL_OLD) return {L->vel[L->old_alias], L->has_temporal ? c * 3 * 4 : 0, 3, 4};
     }
     switch (field) {
-    case LUDWIG_F: return {L->f[0], c * Q * 4};
-    case LUDWIG_F_TEMP: return {L->f[1], c * Q * 4};
-    case LUDWIG_F_POST: return {L->f_post, L->has_post ? c * Q * 4 : 0};
-    case LUDWIG_F_OLD: return {L->f_old, L->has_temporal ? c * Q * 4 : 0};
-    case LUDWIG_RHO: return {L->rho, c * 4};
-    case LUDWIG_RHO_OLD: return {L->rho_old, L->has_temporal ? c * 4 : 0};
-    case LUDWIG_VEL: return {L->vel[0], c * 3 * 4};
-    case LUDWIG_VEL_TEMP: return {L->vel[1], c * 3 * 4};
-    case LUDWIG_VEL_OLD: return {L->vel_old, L->has_temporal ? c * 3 * 4 : 0};
-    case LUDWIG_OBSTACLE: return {L->obstacle, c};
-    case LUDWIG_SPONGE: return {L->sponge, c * 4};
-    case LUDWIG_WALL_DIST: return {L->wall_dist, c * 4};
-    default: return {nullptr, 0};
+    case LUDWIG_F: return {L->f[0], c * Q * 4, Q, 4};
+    case LUDWIG_F_TEMP: return {L->f[1], c * Q * 4, Q, 4};
+    case LUDWIG_F_POST: return {L->f_post, L->has_post ? c * Q * 4 : 0, Q, 4};
+    case LUDWIG_F_OLD: return {L->f_old, L->has_temporal ? c * Q * 4 : 0, Q, 4};
+    case LUDWIG_RHO: return {L->rho, c * 4, 1, 4};
+    case LUDWIG_RHO_OLD: return {L->rho_old, L->has_temporal ? c * 4 : 0, 1, 4};
+    case LUDWIG_VEL: return {L->vel[0], c * 3 * 4, 3, 4};
+    case LUDWIG_VEL_TEMP: return {L->vel[1], c * 3 * 4, 3, 4};
+    case LUDWIG_VEL_OLD: return {L->vel_old, L->has_temporal ? c * 3 * 4 : 0, 3, 4};
+    case LUDWIG_OBSTACLE: return {L->obstacle, c, 1, 1};
+    case LUDWIG_SPONGE: return {L->sponge, c * 4, 1, 4};
+    case LUDWIG_WALL_DIST: return {L->wall_dist, c * 4, 1, 4};
+    default: return {nullptr, 0, 1, 4};
     }
 }
 
@@ -298,14 +300,9 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
             if (!block_in_part(L, b, part)) return fail(LUDWIG_ERR_INVALID, "work item %lld: block %d is not in part %d", (long long)i, b, part);
         }
     }
-    const bool use_xrun = getenv("LUDWIG_NO_XRUN") == nullptr;
-    L->general_in_runs[part] = use_xrun;
-    if (!use_xrun) {                                    // diagnostics: everything wave by wave
-        for (int64_t i = 0; i < n; ++i) {
-            if (items[i] < 0) cls[0].push_back(-1);
-            else cls[is_fast(items[i] >> 3) ? 0 : 1].push_back(items[i]);
-        }
-    } else {
+    const bool use_xrun = true;
+    L->general_in_runs[part] = true;
+    {
         // All-neighbour blocks -> x-run kernel (class 2), XRUN waves per workgroup; a wave is LINKED to the next one when
         // that one holds its +x neighbour block at the same plane (then the face column travels through LDS). Workgroups
         // of the caller's order that hold only such blocks keep their composition (and with it their XCD slot); loose
@@ -352,7 +349,7 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
         bool any = false;
         for (int32_t it : cls[c]) any = any || it >= 0;
         if (!any) cls[c].clear();
-        while (cls[c].size() % (c == 0 ? 4 : XRUN)) cls[c].push_back(-1);
+        while (cls[c].size() % XRUN) cls[c].push_back(-1);
         if (L->items[part][c]) { (void)hipFree(L->items[part][c]); L->items[part][c] = nullptr; }
         L->n_items[part][c] = (int64_t)cls[c].size();
         if (!cls[c].empty()) {
@@ -568,7 +565,6 @@ static void fill_parent_params(SCParams &p, const LudwigLevel *parent, int64_t t
         p.pf_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->f[parent->old_alias] : parent->f_old) : parent->f[pout];
         p.prho_old = parent->has_temporal ? parent->rho_old : parent->rho;
         p.pvel_old = parent->has_temporal ? (parent->old_alias >= 0 ? parent->vel[parent->old_alias] : parent->vel_old) : parent->vel[pout];
-        p.psk = parent->sk;
         p.is_level_1 = 0;
     } else {
         p.is_level_1 = 1;
@@ -679,7 +675,6 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     p.sponge = L->sponge;
     p.wall_dist = L->wall_dist;
     p.meta = L->meta;
-    p.sk = L->sk;
     fill_parent_params(p, parent, t_sub);
     p.tau = L->tau;
     p.tau_parent = parent_tau;
@@ -705,7 +700,7 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         if (r) return r;
     }
     {
-        static const bool eager_env = getenv("LUDWIG_EAGER_RHO") != nullptr || getenv("LUDWIG_NO_XRUN") != nullptr;
+        static const bool eager_env = getenv("LUDWIG_EAGER_RHO") != nullptr;
         if (t_sub != L->last_step_t) { ++L->step_count; L->last_step_t = t_sub; }
         const bool store = L->rho_eager || eager_env || part != LUDWIG_PART_ALL;
         // This launch reuses the previous step's INPUT buffer as its output. A whole-level launch supersedes the elided rho of
@@ -724,29 +719,27 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         const int r = interface_pass(L, parent, part, p, t_sub, parent_tau, temporal_weight, false);
         if (r) return r;
     }
-    for (int c = 0; c < N_CLASSES; ++c) {
+    for (int c = 1; c < N_CLASSES; ++c) {
         if (L->n_items[part][c] == 0) continue;
         p.items = L->items[part][c];
-        const dim3 grid((unsigned)(L->n_items[part][c] / 4)), block(256);
+        const dim3 grid((unsigned)(L->n_items[part][c] / XRUN)), block(64 * XRUN);
         const hipStream_t cs = L->stream;
-#define LW_LAUNCH(G, P, W) hipLaunchKernelGGL((k_stream_collide<G, P, W>), grid, block, 0, cs, p)
-#define LW_LAUNCH_X(G, P, W) do { if (XRUN == 8) hipLaunchKernelGGL((k_stream_collide_xrun<8, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 8)), dim3(512), 0, cs, p); \
-            else hipLaunchKernelGGL((k_stream_collide_xrun<4, G, P, W>), dim3((unsigned)(L->n_items[part][c] / 4)), dim3(256), 0, cs, p); } while (0)
-        if (c == 0) {
-            if (post) { if (wall) LW_LAUNCH(false, true, true); else LW_LAUNCH(false, true, false); }
-            else      { if (wall) LW_LAUNCH(false, false, true); else LW_LAUNCH(false, false, false); }
-        } else if (c == 1 && !L->general_in_runs[part]) {
-            if (post) { if (wall) LW_LAUNCH(true, true, true); else LW_LAUNCH(true, true, false); }
-            else      { if (wall) LW_LAUNCH(true, false, true); else LW_LAUNCH(true, false, false); }
-        } else if (c == 1) {
-            if (post) { if (wall) LW_LAUNCH_X(true, true, true); else LW_LAUNCH_X(true, true, false); }
-            else      { if (wall) LW_LAUNCH_X(true, false, true); else LW_LAUNCH_X(true, false, false); }
+        const bool general = c == 1;
+#define LW_LAUNCH_X(G, P, W) do { if (L->wide) hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, G, P, W, false, true>), grid, block, 0, cs, p); \
+            else hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, G, P, W, false, false>), grid, block, 0, cs, p); } while (0)
+        // WALL without POST goes through the <POST, WALL> instantiation (no block is flagged for the f_post store, so the null
+        // pointer is never used): the register allocator gets <POST = false, WALL = true> down to 96 VGPRs only by spilling
+        // 208 B per lane, while the POST variant sits at 88-90 without - same arithmetic, same bits
+        if (general) {
+            if (wall) LW_LAUNCH_X(true, true, true);
+            else if (post) LW_LAUNCH_X(true, true, false);
+            else LW_LAUNCH_X(true, false, false);
         } else {
-            if (post) { if (wall) LW_LAUNCH_X(false, true, true); else LW_LAUNCH_X(false, true, false); }
-            else      { if (wall) LW_LAUNCH_X(false, false, true); else LW_LAUNCH_X(false, false, false); }
+            if (wall) LW_LAUNCH_X(false, true, true);
+            else if (post) LW_LAUNCH_X(false, true, false);
+            else LW_LAUNCH_X(false, false, false);
         }
 #undef LW_LAUNCH_X
-#undef LW_LAUNCH
         LW_HIP(hipGetLastError());
     }
     if (!p.store_rho) {
@@ -778,13 +771,13 @@ int ensure_rho(LudwigLevel *L)
             if (L->n_items[part][c] == 0) continue;
             p.items = L->items[part][c];
             const bool general = c == 1;
-            const dim3 g4((unsigned)(L->n_items[part][c] / 4)), g8((unsigned)(L->n_items[part][c] / 8));
-            if (XRUN == 8) {
-                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<8, true, false, false, true>), g8, dim3(512), 0, L->stream, p);
-                else hipLaunchKernelGGL((k_stream_collide_xrun<8, false, false, false, true>), g8, dim3(512), 0, L->stream, p);
+            const dim3 grid((unsigned)(L->n_items[part][c] / XRUN)), block(64 * XRUN);
+            if (L->wide) {
+                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, true, false, false, true, true>), grid, block, 0, L->stream, p);
+                else hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, false, false, false, true, true>), grid, block, 0, L->stream, p);
             } else {
-                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<4, true, false, false, true>), g4, dim3(256), 0, L->stream, p);
-                else hipLaunchKernelGGL((k_stream_collide_xrun<4, false, false, false, true>), g4, dim3(256), 0, L->stream, p);
+                if (general) hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, true, false, false, true, false>), grid, block, 0, L->stream, p);
+                else hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, false, false, false, true, false>), grid, block, 0, L->stream, p);
             }
             LW_HIP(hipGetLastError());
         }
@@ -807,7 +800,6 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
     p.cell_block = L->cell_block;
     p.cell_x = L->cell_x; p.cell_y = L->cell_y; p.cell_z = L->cell_z;
     p.meta = L->meta;
-    p.sk = L->sk;
     p.n_cells = L->n_bc;
     // q > q_min with q_min >= 0 can only hold where q > 0: the compact list; a negative threshold takes every (cell, k)
     const bool compact = q_min >= 0.0f && L->bouzidi_links;
@@ -821,53 +813,41 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
     return LUDWIG_OK;
 }
 
-// Host <-> device copy of a whole field between the caller's array (reference block order, population stride sk_ref) and the
-// device array (internal block order, population stride sk). Same order and same stride: one copy; otherwise one population /
-// component at a time, through `scratch` and a block-permuting kernel when the orders differ. es = element size (1: obstacle,
+// Host <-> device copy of a whole field between the caller's array (reference layout: population-major, reference block order)
+// and the device array (block-major, internal block order). One component and the same block order: one copy; otherwise one
+// component at a time through `scratch` and a kernel that places every block. K = components, es = element size (1: obstacle,
 // 2: q map, else 4). Synchronous on the level's stream.
-int copy_field(LudwigLevel *L, void *dev, void *host, size_t bytes, size_t es, bool to_device)
+int copy_field(LudwigLevel *L, void *dev, void *host, int K, size_t es, bool to_device)
 {
-    const size_t hplane = (size_t)L->sk_ref * es, dplane = (size_t)L->sk * es;     // one population in bytes, host / device
-    const size_t K = hplane ? bytes / hplane : 0;
-    const bool permute = !L->ref2int.empty();
-    if (!permute && (L->sk == L->sk_ref || K <= 1)) {
-        if (to_device) LW_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, L->stream));
-        else LW_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, L->stream));
+    const size_t plane = (size_t)L->sk * es;                   // one component in bytes
+    if (plane == 0) return LUDWIG_OK;
+    if (K == 1 && !L->d_ref2int) {
+        if (to_device) LW_HIP(hipMemcpyAsync(dev, host, plane, hipMemcpyHostToDevice, L->stream));
+        else LW_HIP(hipMemcpyAsync(host, dev, plane, hipMemcpyDeviceToHost, L->stream));
         LW_HIP(hipStreamSynchronize(L->stream));
         return LUDWIG_OK;
     }
-    if (permute && !L->scratch) LW_HIP(hipMalloc(&L->scratch, (size_t)L->sk_ref * 4));
-    const int64_t n = L->sk_ref;
+    if (!L->scratch) LW_HIP(hipMalloc(&L->scratch, (size_t)L->sk * 4));
+    const int64_t n = L->sk;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
-    for (size_t k = 0; k < K; ++k) {
-        char *d = (char *)dev + k * dplane, *h = (char *)host + k * hplane;
-        if (!permute) {
-            if (to_device) LW_HIP(hipMemcpyAsync(d, h, hplane, hipMemcpyHostToDevice, L->stream));
-            else LW_HIP(hipMemcpyAsync(h, d, hplane, hipMemcpyDeviceToHost, L->stream));
-        } else if (to_device) {
-            LW_HIP(hipMemcpyAsync(L->scratch, h, hplane, hipMemcpyHostToDevice, L->stream));
-            if (es == 1) hipLaunchKernelGGL(k_blocks_to_internal<uint8_t>, grid, block, 0, L->stream, (uint8_t *)d, (const uint8_t *)L->scratch, L->d_ref2int, n);
-            else if (es == 2) hipLaunchKernelGGL(k_blocks_to_internal<uint16_t>, grid, block, 0, L->stream, (uint16_t *)d, (const uint16_t *)L->scratch, L->d_ref2int, n);
-            else hipLaunchKernelGGL(k_blocks_to_internal<float>, grid, block, 0, L->stream, (float *)d, (const float *)L->scratch, L->d_ref2int, n);
+    for (int k = 0; k < K; ++k) {
+        char *h = (char *)host + (size_t)k * plane;
+        if (to_device) {
+            LW_HIP(hipMemcpyAsync(L->scratch, h, plane, hipMemcpyHostToDevice, L->stream));
+            if (es == 1) hipLaunchKernelGGL(k_component_to_internal<uint8_t>, grid, block, 0, L->stream, (uint8_t *)dev, (const uint8_t *)L->scratch, L->d_ref2int, n, K, k);
+            else if (es == 2) hipLaunchKernelGGL(k_component_to_internal<uint16_t>, grid, block, 0, L->stream, (uint16_t *)dev, (const uint16_t *)L->scratch, L->d_ref2int, n, K, k);
+            else hipLaunchKernelGGL(k_component_to_internal<float>, grid, block, 0, L->stream, (float *)dev, (const float *)L->scratch, L->d_ref2int, n, K, k);
         } else {
-            if (es == 1) hipLaunchKernelGGL(k_blocks_to_reference<uint8_t>, grid, block, 0, L->stream, (uint8_t *)L->scratch, (const uint8_t *)d, L->d_ref2int, n);
-            else if (es == 2) hipLaunchKernelGGL(k_blocks_to_reference<uint16_t>, grid, block, 0, L->stream, (uint16_t *)L->scratch, (const uint16_t *)d, L->d_ref2int, n);
-            else hipLaunchKernelGGL(k_blocks_to_reference<float>, grid, block, 0, L->stream, (float *)L->scratch, (const float *)d, L->d_ref2int, n);
-            LW_HIP(hipMemcpyAsync(h, L->scratch, hplane, hipMemcpyDeviceToHost, L->stream));
+            if (es == 1) hipLaunchKernelGGL(k_component_to_reference<uint8_t>, grid, block, 0, L->stream, (uint8_t *)L->scratch, (const uint8_t *)dev, L->d_ref2int, n, K, k);
+            else if (es == 2) hipLaunchKernelGGL(k_component_to_reference<uint16_t>, grid, block, 0, L->stream, (uint16_t *)L->scratch, (const uint16_t *)dev, L->d_ref2int, n, K, k);
+            else hipLaunchKernelGGL(k_component_to_reference<float>, grid, block, 0, L->stream, (float *)L->scratch, (const float *)dev, L->d_ref2int, n, K, k);
+            LW_HIP(hipMemcpyAsync(h, L->scratch, plane, hipMemcpyDeviceToHost, L->stream));
             LW_HIP(hipStreamSynchronize(L->stream));          // pageable destination: the copy must be over before scratch is reused
         }
         LW_HIP(hipGetLastError());
     }
     LW_HIP(hipStreamSynchronize(L->stream));
     return LUDWIG_OK;
-}
-
-// Distance between two populations in device memory, in blocks (x 2 KiB): n_blocks plus padding. LUDWIG_STRIDE_PAD_BLOCKS=k
-// overrides the rule (0 = the reference's own stride).
-int64_t choose_stride_blocks(int64_t n_blocks)
-{
-    if (const char *e = getenv("LUDWIG_STRIDE_PAD_BLOCKS")) return n_blocks + std::max(0, atoi(e));
-    return n_blocks;
 }
 
 }  // namespace
@@ -1023,9 +1003,9 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
     L->n_owned = n_owned;
     L->tau = h->tau;
     L->gdx = h->grid_dim_x; L->gdy = h->grid_dim_y; L->gdz = h->grid_dim_z;
-    L->sk_ref = (int64_t)h->n_blocks * CELLS;
-    L->sk = choose_stride_blocks(h->n_blocks) * CELLS;
-    const size_t c = (size_t)L->sk, cr = (size_t)L->sk_ref, nb = (size_t)h->n_blocks;
+    L->sk = (int64_t)h->n_blocks * CELLS;
+    L->wide = (int64_t)h->n_blocks * (int64_t)F_BLOCK_BYTES >= ((int64_t)1 << 32) || getenv("LUDWIG_WIDE_ADDR") != nullptr;
+    const size_t c = (size_t)L->sk, nb = (size_t)h->n_blocks;
     L->has_temporal = h->enable_temporal_interpolation && nb > 0;            // reference src/blocks.jl:123
     L->bouzidi_enabled = h->n_boundary_cells > 0 && h->bouzidi_q_map;        // reference src/blocks.jl:152
     L->n_bc = L->bouzidi_enabled ? h->n_boundary_cells : 0;
@@ -1101,17 +1081,19 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             LW_HIP(hipMemsetAsync(L->vel_old, 0, c * 3 * 4, L->stream));
             if ((r = fill(L, L->rho_old, L->sk, 1.0f))) return r;
         }
-        if (h->obstacle) LW_HIP(hipMemcpyAsync(L->obstacle, h->obstacle, cr, hipMemcpyHostToDevice, L->stream));
+        if (h->obstacle) LW_HIP(hipMemcpyAsync(L->obstacle, h->obstacle, c, hipMemcpyHostToDevice, L->stream));
         else LW_HIP(hipMemsetAsync(L->obstacle, 0, c, L->stream));
-        if (h->sponge) LW_HIP(hipMemcpyAsync(L->sponge, h->sponge, cr * 4, hipMemcpyHostToDevice, L->stream));
+        if (h->sponge) LW_HIP(hipMemcpyAsync(L->sponge, h->sponge, c * 4, hipMemcpyHostToDevice, L->stream));
         else LW_HIP(hipMemsetAsync(L->sponge, 0, c * 4, L->stream));
-        if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, cr * 4, hipMemcpyHostToDevice, L->stream));
+        if (h->wall_dist) LW_HIP(hipMemcpyAsync(L->wall_dist, h->wall_dist, c * 4, hipMemcpyHostToDevice, L->stream));
         else if ((r = fill(L, L->wall_dist, L->sk, 100.0f))) return r;
         // block_pointer stays on the host: its only use is the static corner lookup of a child's interface links
         if (h->block_pointer && nptr > 0) L->h_block_pointer.assign(h->block_pointer, h->block_pointer + nptr);
         if (L->bouzidi_enabled) {
-            for (int k = 0; k < Q; ++k)       // host: population stride sk_ref, device: sk
-                LW_HIP(hipMemcpyAsync(L->q_map + c * k, h->bouzidi_q_map + cr * k, cr * 2, hipMemcpyHostToDevice, L->stream));
+            {   // host: population-major (already in the internal block order here), device: block-major
+                const int r = copy_field(L, L->q_map, const_cast<uint16_t *>(h->bouzidi_q_map), Q, 2, true);
+                if (r) return r;
+            }
             std::vector<int32_t> cb((size_t)L->n_bc);
             std::vector<int8_t> cx((size_t)L->n_bc), cy((size_t)L->n_bc), cz((size_t)L->n_bc);
             for (int i = 0; i < L->n_bc; ++i) {
@@ -1129,7 +1111,7 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             for (int i = 0; i < L->n_bc; ++i) {
                 const int own = cb[i] * CELLS + cx[i] + 8 * cy[i] + 64 * cz[i];
                 for (int k = 0; k < Q; ++k)
-                    if ((float)qh[(size_t)own + cr * k] > 0.0f) bl.push_back(make_int2(own, k));
+                    if ((float)qh[(size_t)own + c * k] > 0.0f) bl.push_back(make_int2(own, k));
             }
             L->n_bouzidi_links = (int)bl.size();
             if (!bl.empty()) {
@@ -1262,9 +1244,10 @@ int ludwig_level_upload(LudwigLevel *L, int field, const void *host, size_t byte
         const int r = before_external_write(L, field);
         if (r) return r;
     }
-    const size_t es = field == LUDWIG_OBSTACLE ? 1 : 4;
+    const size_t es = (size_t)d.es;
     {
-        const int r = copy_field(L, field_desc(L, field).ptr, const_cast<void *>(host), bytes, es, true);
+        const FieldDesc dn = field_desc(L, field);             // after before_external_write: the saved state may have moved
+        const int r = copy_field(L, dn.ptr, const_cast<void *>(host), dn.comps, es, true);
         if (r) return r;
     }
     if (field == LUDWIG_OBSTACLE || field == LUDWIG_SPONGE || field == LUDWIG_WALL_DIST) {
@@ -1292,7 +1275,7 @@ int ludwig_level_download(const LudwigLevel *L, int field, void *host, size_t by
         const int r = ensure_rho(const_cast<LudwigLevel *>(L));
         if (r) return r;
     }
-    return copy_field(const_cast<LudwigLevel *>(L), d.ptr, host, bytes, field == LUDWIG_OBSTACLE ? 1 : 4, false);
+    return copy_field(const_cast<LudwigLevel *>(L), d.ptr, host, d.comps, (size_t)d.es, false);
 }
 
 int ludwig_level_block_order(const LudwigLevel *L, int32_t *ref_to_internal)
@@ -1318,7 +1301,7 @@ int ludwig_level_field_ptr(const LudwigLevel *L, int field, void **device_ptr, s
         m->rho_eager = true;
     }
     *device_ptr = d.ptr;
-    if (bytes) *bytes = L->sk_ref > 0 ? d.bytes / (size_t)L->sk_ref * (size_t)L->sk : d.bytes;   // the device array: comps x sk elements
+    if (bytes) *bytes = d.bytes;
     return LUDWIG_OK;
 }
 
@@ -1336,10 +1319,14 @@ int ludwig_level_set_rho_store(LudwigLevel *L, int every_step)
     return LUDWIG_OK;
 }
 
-int ludwig_level_population_stride(const LudwigLevel *L, int64_t *elements)
+int ludwig_level_field_layout(const LudwigLevel *L, int field, int32_t *components, int64_t *block_stride, int64_t *component_stride)
 {
-    if (!L || !elements) return fail(LUDWIG_ERR_INVALID, "null argument");
-    *elements = L->sk;
+    if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
+    const FieldDesc d = field_desc(L, field);
+    if (field < 0 || field >= LUDWIG_FIELD_COUNT) return fail(LUDWIG_ERR_INVALID, "bad field %d", field);
+    if (components) *components = d.comps;
+    if (block_stride) *block_stride = (int64_t)d.comps * CELLS;      // block-major: the components of a block are contiguous
+    if (component_stride) *component_stride = CELLS;
     return LUDWIG_OK;
 }
 
@@ -1562,7 +1549,6 @@ int ludwig_map_surface_stresses(const LudwigLevel *L, int vel_field, int32_t n_t
         s.vel = L->vel[vel_field == LUDWIG_VEL ? 0 : 1];
         s.obstacle = L->obstacle;
         s.block_pointer = d_ptr;
-        s.sk = L->sk;
         s.gdx = L->gdx; s.gdy = L->gdy; s.gdz = L->gdz; s.n_tri = n_tri; s.radius = sp->search_radius;
         s.dx = sp->dx; s.tau = sp->tau; s.off_x = sp->offset_x; s.off_y = sp->offset_y; s.off_z = sp->offset_z;
         s.pressure_scale = sp->pressure_scale; s.stress_scale = sp->stress_scale;
@@ -1623,7 +1609,7 @@ int ludwig_halo_pack(const LudwigLevel *L, int field, const int64_t *index_dev, 
         // the replay ran on the level's stream: a pack queued on another stream must not overtake it
         if (stale && hip_stream && (hipStream_t)hip_stream != L->stream) LW_HIP(hipStreamSynchronize(L->stream));
     }
-    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev, (const int32_t *)L->d_ref2int, L->sk_ref, L->sk);
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (const float *)d.ptr, index_dev, n, dst_dev, (const int32_t *)L->d_ref2int, L->sk, d.comps);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -1642,7 +1628,7 @@ int ludwig_halo_unpack(LudwigLevel *L, int field, const int64_t *index_dev, int6
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || field == LUDWIG_OBSTACLE) return fail(LUDWIG_ERR_STATE, "field %d cannot be unpacked", field);
     LW_HIP(hipSetDevice(L->device));
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev, (const int32_t *)L->d_ref2int, L->sk_ref, L->sk);
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, hip_stream ? (hipStream_t)hip_stream : L->stream, (float *)d.ptr, index_dev, n, src_dev, (const int32_t *)L->d_ref2int, L->sk, d.comps);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -1660,6 +1646,464 @@ int ludwig_level_info(const LudwigLevel *L, LudwigLevelInfo *info)
     info->n_xrun_blocks = (int32_t)(L->n_linked_items[LUDWIG_PART_ALL] / 8);   // 8 planes per block
     info->device_bytes = L->device_bytes;
     return LUDWIG_OK;
+}
+
+// ============================================================================================================================
+// Multi-GPU: communicator, halo plan, exchange, distributed step (include/ludwig_hip.h "multi-GPU")
+// ============================================================================================================================
+}  // extern "C"  (helpers below are internal)
+
+#include <dlfcn.h>
+#include <link.h>
+#include <rccl/rccl.h>      // types and prototypes only: the functions are resolved at run time, the library is not linked
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    std::string path;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *data)
+{
+    if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
+        *static_cast<std::string *>(data) = info->dlpi_name;
+        return 1;
+    }
+    return 0;
+}
+
+// The RCCL already mapped into the process wins (a host that also uses PyTorch has torch's copy loaded, and two RCCLs in one process
+// each bring their own kernels, proxy threads and IPC state); else LUDWIG_RCCL_LIB, else the loader's librccl.so.1 / librccl.so.
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    std::string loaded;
+    dl_iterate_phdr(find_loaded_rccl, &loaded);
+    const char *env = getenv("LUDWIG_RCCL_LIB");
+    std::vector<std::string> names;
+    if (!loaded.empty()) names.push_back(loaded);
+    if (env) names.push_back(env);
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
+    for (const std::string &n : names) {
+        void *h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) continue;
+        api.handle = h;
+        api.path = n;
+        break;
+    }
+    if (!api.handle) { g_err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return nullptr; }
+#define LW_SYM(f) api.f = reinterpret_cast<decltype(api.f)>(dlsym(api.handle, "nccl" #f)); if (!api.f) { g_err = "librccl lacks nccl" #f; api.handle = nullptr; return nullptr; }
+    LW_SYM(GetUniqueId) LW_SYM(CommInitRank) LW_SYM(CommDestroy) LW_SYM(GroupStart) LW_SYM(GroupEnd) LW_SYM(Send) LW_SYM(Recv)
+    LW_SYM(AllReduce) LW_SYM(GetErrorString)
+#undef LW_SYM
+    return &api;
+}
+
+#define LW_NCCL(api, call)                                                                                          \
+    do {                                                                                                            \
+        ncclResult_t r_ = (call);                                                                                   \
+        if (r_ != ncclSuccess) return fail(LUDWIG_ERR_HIP, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int HALO_GROUP_COMPS[LUDWIG_HALO_GROUPS] = {Q, 3, Q, 1};      // populations, velocity, f_post_collision, rho
+constexpr int TIMING_RING = 256;
+
+}  // namespace
+
+struct LudwigComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;       // small collectives (diagnostics)
+    float *scratch = nullptr;           // device, 2 x 256 floats
+};
+
+struct LudwigHaloPlan {
+    LudwigLevel *L = nullptr;
+    LudwigComm *comm = nullptr;
+    std::vector<int32_t> peers;
+    struct Group {
+        int64_t n_send = 0, n_recv = 0, n_send_oct = 0, n_recv_oct = 0;
+        float *send_buf = nullptr, *recv_buf = nullptr;
+        uint4 *send_desc = nullptr, *recv_desc = nullptr;
+        std::vector<int64_t> send_off, recv_off;       // [n_peers + 1] prefix sums
+    } g[LUDWIG_HALO_GROUPS];
+    hipStream_t s_comm = nullptr;                      // high priority: a queue of its own beside the stepping stream
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    bool pending = false;                              // an exchange has been queued since the last wait
+    bool self_via_rccl = false;                        // LUDWIG_HALO_SELF_VIA_RCCL: messages to this rank itself go through ncclSend / ncclRecv
+    bool timing = false;
+    hipEvent_t t0[TIMING_RING] = {}, t1[TIMING_RING] = {};
+    int64_t n_timed = 0, n_read = 0;
+};
+
+namespace {
+
+// message elements (reference-layout offsets, in message order) -> octet descriptors of the device array (kernels.hpp: k_pack_octets)
+int build_octets(const LudwigLevel *L, int K, const int64_t *index, int64_t n, std::vector<uint4> &out)
+{
+    out.clear();
+    const int64_t sk = L->sk, total = sk * K;
+    int64_t cur_oct = -1;
+    int last_j = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t off = index[i];
+        if (off < 0 || off >= total) return fail(LUDWIG_ERR_INVALID, "halo plan: element offset %lld outside the field (%lld elements)", (long long)off, (long long)total);
+        const int64_t k = off / sk, r = off - k * sk;
+        const int64_t blk = L->ref2int.empty() ? (r >> 9) : (int64_t)L->ref2int[(size_t)(r >> 9)];
+        const int64_t in = (blk * K + k) * CELLS + (r & 511);
+        const int64_t oct = in >> 3;
+        const int j = (int)(in & 7);
+        if (oct != cur_oct || j <= last_j) {             // a new sector, or not ascending inside it: a new descriptor
+            if (oct >= ((int64_t)1 << 32) || i >= ((int64_t)1 << 32)) return fail(LUDWIG_ERR_INVALID, "halo plan: level too large for 32-bit octet descriptors");
+            out.push_back(make_uint4((uint32_t)oct, (uint32_t)i, 0u, 0u));
+            cur_oct = oct;
+        }
+        out.back().z |= 1u << j;
+        last_j = j;
+    }
+    return LUDWIG_OK;
+}
+
+int halo_pack_group(LudwigHaloPlan *P, int group, int field, hipStream_t st)
+{
+    LudwigLevel *L = P->L;
+    LudwigHaloPlan::Group &G = P->g[group];
+    if (G.n_send_oct == 0) return LUDWIG_OK;
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || d.es != 4 || d.comps != HALO_GROUP_COMPS[group]) return fail(LUDWIG_ERR_INVALID, "halo group %d cannot move field %d", group, field);
+    hipLaunchKernelGGL(k_pack_octets, dim3((unsigned)((G.n_send_oct * 8 + 255) / 256)), dim3(256), 0, st, (const float *)d.ptr, G.send_desc, G.n_send_oct, G.send_buf);
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+int halo_unpack_group(LudwigHaloPlan *P, int group, int field, hipStream_t st)
+{
+    LudwigLevel *L = P->L;
+    LudwigHaloPlan::Group &G = P->g[group];
+    if (G.n_recv_oct == 0) return LUDWIG_OK;
+    const FieldDesc d = field_desc(L, field);
+    if (!d.ptr || d.es != 4 || d.comps != HALO_GROUP_COMPS[group]) return fail(LUDWIG_ERR_INVALID, "halo group %d cannot move field %d", group, field);
+    hipLaunchKernelGGL(k_unpack_octets, dim3((unsigned)((G.n_recv_oct * 8 + 255) / 256)), dim3(256), 0, st, (float *)d.ptr, G.recv_desc, G.n_recv_oct, G.recv_buf);
+    LW_HIP(hipGetLastError());
+    return LUDWIG_OK;
+}
+
+// what has to be true on the LEVEL's stream before an exchange may read `field` (pack side) / write its ghosts (unpack side)
+int halo_prepare_field(LudwigLevel *L, int group, int field)
+{
+    if (field == LUDWIG_RHO) {
+        const int r = ensure_rho(L);                    // an elided rho is produced now, on the level's stream
+        if (r) return r;
+    }
+    (void)group;
+    return before_external_write(L, field);             // the ghosts of `field` are about to be written: saved-state alias, lazy rho inputs
+}
+
+}  // namespace
+
+extern "C" {
+
+int ludwig_comm_unique_id(void *id_out)
+{
+    if (!id_out) return fail(LUDWIG_ERR_INVALID, "null argument");
+    RcclApi *api = rccl();
+    if (!api) return fail(LUDWIG_ERR_STATE, "RCCL unavailable: %s", g_err.c_str());
+    static_assert(sizeof(ncclUniqueId) == LUDWIG_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    LW_NCCL(api, api->GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return LUDWIG_OK;
+}
+
+int ludwig_comm_create(const void *unique_id, int rank, int world, int device, LudwigComm **out)
+{
+    if (out) *out = nullptr;
+    if (!unique_id || !out || world < 1 || rank < 0 || rank >= world) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    RcclApi *api = rccl();
+    if (!api) return fail(LUDWIG_ERR_STATE, "RCCL unavailable: %s", g_err.c_str());
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(LUDWIG_ERR_NO_DEVICE, "no HIP device %d", device);
+    LW_HIP(hipSetDevice(device));
+    LudwigComm *c = new (std::nothrow) LudwigComm();
+    if (!c) return fail(LUDWIG_ERR_ALLOC, "host allocation failed");
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof id);
+    ncclResult_t r = api->CommInitRank(&c->comm, world, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(LUDWIG_ERR_HIP, "ncclCommInitRank: %s", api->GetErrorString(r)); }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->scratch, 512 * sizeof(float));
+    if (e != hipSuccess) { ludwig_comm_destroy(c); return fail(LUDWIG_ERR_HIP, "communicator set-up: %s", hipGetErrorString(e)); }
+    *out = c;
+    return LUDWIG_OK;
+}
+
+void ludwig_comm_destroy(LudwigComm *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    RcclApi *api = rccl();
+    if (c->comm && api) (void)api->CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int ludwig_comm_allreduce_f32(LudwigComm *c, float *buf, int32_t n, int32_t op)
+{
+    if (!c || !buf || n < 0 || n > 256) return fail(LUDWIG_ERR_INVALID, "bad argument (at most 256 values)");
+    if (op != 0 && op != 2 && op != 3) return fail(LUDWIG_ERR_INVALID, "op must be 0 (sum), 2 (max) or 3 (min)");
+    if (n == 0) return LUDWIG_OK;
+    RcclApi *api = rccl();
+    if (!api) return fail(LUDWIG_ERR_STATE, "RCCL unavailable");
+    LW_HIP(hipSetDevice(c->device));
+    // min / max: what the backend makes of a NaN is its own business, so NaN travels as a flag (second reduction, max)
+    float host[512];
+    for (int i = 0; i < n; ++i) {
+        const bool nan = buf[i] != buf[i];
+        host[i] = (nan && op != 0) ? (op == 3 ? __builtin_inff() : -__builtin_inff()) : buf[i];
+        host[256 + i] = nan ? 1.0f : 0.0f;
+    }
+    LW_HIP(hipMemcpyAsync(c->scratch, host, 512 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    LW_NCCL(api, api->AllReduce(c->scratch, c->scratch, (size_t)n, ncclFloat, (ncclRedOp_t)op, c->comm, c->stream));
+    if (op != 0) LW_NCCL(api, api->AllReduce(c->scratch + 256, c->scratch + 256, (size_t)n, ncclFloat, ncclMax, c->comm, c->stream));
+    LW_HIP(hipMemcpyAsync(host, c->scratch, 512 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    LW_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; ++i) buf[i] = (op != 0 && host[256 + i] > 0.0f) ? __builtin_nanf("") : host[i];
+    return LUDWIG_OK;
+}
+
+void ludwig_halo_plan_destroy(LudwigHaloPlan *P)
+{
+    if (!P) return;
+    if (P->L) (void)hipSetDevice(P->L->device);
+    if (P->s_comm) (void)hipStreamSynchronize(P->s_comm);
+    for (auto &G : P->g) {
+        void *ptrs[] = {G.send_buf, G.recv_buf, G.send_desc, G.recv_desc};
+        for (void *q : ptrs)
+            if (q) (void)hipFree(q);
+    }
+    for (int i = 0; i < TIMING_RING; ++i) {
+        if (P->t0[i]) (void)hipEventDestroy(P->t0[i]);
+        if (P->t1[i]) (void)hipEventDestroy(P->t1[i]);
+    }
+    if (P->ev_ready) (void)hipEventDestroy(P->ev_ready);
+    if (P->ev_done) (void)hipEventDestroy(P->ev_done);
+    if (P->s_comm) (void)hipStreamDestroy(P->s_comm);
+    delete P;
+}
+
+int ludwig_halo_plan_create(LudwigLevel *L, LudwigComm *comm, const LudwigHaloPlanDesc *desc, LudwigHaloPlan **out)
+{
+    if (out) *out = nullptr;
+    if (!L || !desc || !out || desc->n_peers < 0 || (desc->n_peers > 0 && !desc->peer_ranks)) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    if (comm && comm->device != L->device) return fail(LUDWIG_ERR_INVALID, "communicator and level live on different devices");
+    for (int p = 0; p < desc->n_peers; ++p) {
+        const int r = desc->peer_ranks[p];
+        if (comm ? (r < 0 || r >= comm->world) : r != 0) return fail(LUDWIG_ERR_INVALID, "peer %d: rank %d not in the communicator", p, r);
+    }
+    LW_HIP(hipSetDevice(L->device));
+    LudwigHaloPlan *P = new (std::nothrow) LudwigHaloPlan();
+    if (!P) return fail(LUDWIG_ERR_ALLOC, "host allocation failed");
+    P->L = L; P->comm = comm;
+    P->peers.assign(desc->peer_ranks, desc->peer_ranks + desc->n_peers);
+    P->self_via_rccl = comm && getenv("LUDWIG_HALO_SELF_VIA_RCCL") != nullptr;
+    int rc = LUDWIG_OK;
+    auto upload = [&](const std::vector<uint4> &v, uint4 **dst) -> int {
+        *dst = nullptr;
+        if (v.empty()) return LUDWIG_OK;
+        LW_HIP(hipMalloc((void **)dst, v.size() * sizeof(uint4)));
+        LW_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        return LUDWIG_OK;
+    };
+    for (int g = 0; g < LUDWIG_HALO_GROUPS && rc == LUDWIG_OK; ++g) {
+        LudwigHaloPlan::Group &G = P->g[g];
+        G.send_off.assign((size_t)desc->n_peers + 1, 0);
+        G.recv_off.assign((size_t)desc->n_peers + 1, 0);
+        for (int p = 0; p < desc->n_peers; ++p) {
+            const int64_t ns = desc->send_count[g] ? desc->send_count[g][p] : 0, nr = desc->recv_count[g] ? desc->recv_count[g][p] : 0;
+            if (ns < 0 || nr < 0) rc = fail(LUDWIG_ERR_INVALID, "negative count");
+            G.send_off[(size_t)p + 1] = G.send_off[(size_t)p] + ns;
+            G.recv_off[(size_t)p + 1] = G.recv_off[(size_t)p] + nr;
+        }
+        if (rc) break;
+        G.n_send = G.send_off.back(); G.n_recv = G.recv_off.back();
+        if ((G.n_send > 0 && !desc->send_index[g]) || (G.n_recv > 0 && !desc->recv_index[g])) { rc = fail(LUDWIG_ERR_INVALID, "group %d: index list missing", g); break; }
+        if (g == 2 && (G.n_send || G.n_recv) && !L->has_post) { rc = fail(LUDWIG_ERR_STATE, "group 2 (f_post_collision) on a level without that array"); break; }
+        std::vector<uint4> sd, rd;
+        if ((rc = build_octets(L, HALO_GROUP_COMPS[g], desc->send_index[g], G.n_send, sd))) break;
+        if ((rc = build_octets(L, HALO_GROUP_COMPS[g], desc->recv_index[g], G.n_recv, rd))) break;
+        G.n_send_oct = (int64_t)sd.size(); G.n_recv_oct = (int64_t)rd.size();
+        if ((rc = upload(sd, &G.send_desc)) || (rc = upload(rd, &G.recv_desc))) break;
+        hipError_t e = hipSuccess;
+        if (G.n_send) e = hipMalloc((void **)&G.send_buf, (size_t)G.n_send * 4);
+        if (e == hipSuccess && G.n_recv) e = hipMalloc((void **)&G.recv_buf, (size_t)G.n_recv * 4);
+        if (e != hipSuccess) rc = fail(LUDWIG_ERR_ALLOC, "halo buffers: %s", hipGetErrorString(e));
+    }
+    if (rc == LUDWIG_OK) {
+        int pr_least = 0, pr_greatest = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&P->s_comm, hipStreamNonBlocking, pr_greatest);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&P->ev_ready, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&P->ev_done, hipEventDisableTiming);
+        if (e != hipSuccess) rc = fail(LUDWIG_ERR_HIP, "halo plan streams: %s", hipGetErrorString(e));
+    }
+    if (rc) { ludwig_halo_plan_destroy(P); return rc; }
+    *out = P;
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_plan_timing(LudwigHaloPlan *P, int enable)
+{
+    if (!P) return fail(LUDWIG_ERR_INVALID, "null plan");
+    LW_HIP(hipSetDevice(P->L->device));
+    if (enable && !P->t0[0])
+        for (int i = 0; i < TIMING_RING; ++i) { LW_HIP(hipEventCreate(&P->t0[i])); LW_HIP(hipEventCreate(&P->t1[i])); }
+    P->timing = enable != 0;
+    P->n_read = P->n_timed;
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_plan_exchange_ms(LudwigHaloPlan *P, float *ms_out, int32_t max, int32_t *n_out)
+{
+    if (!P || !n_out || (max > 0 && !ms_out)) return fail(LUDWIG_ERR_INVALID, "null argument");
+    *n_out = 0;
+    if (P->n_timed - P->n_read > TIMING_RING) P->n_read = P->n_timed - TIMING_RING;
+    while (P->n_read < P->n_timed && *n_out < max) {
+        const int i = (int)(P->n_read % TIMING_RING);
+        float ms = 0.0f;
+        LW_HIP(hipEventElapsedTime(&ms, P->t0[i], P->t1[i]));
+        ms_out[(*n_out)++] = ms;
+        ++P->n_read;
+    }
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_plan_pack(LudwigHaloPlan *P, int32_t group, int32_t field, void *hip_stream)
+{
+    if (!P || group < 0 || group >= LUDWIG_HALO_GROUPS) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    LW_HIP(hipSetDevice(P->L->device));
+    if (field == LUDWIG_RHO) { const int r = ensure_rho(P->L); if (r) return r; }
+    return halo_pack_group(P, group, field, hip_stream ? (hipStream_t)hip_stream : P->L->stream);
+}
+
+int ludwig_halo_plan_unpack(LudwigHaloPlan *P, int32_t group, int32_t field, void *hip_stream)
+{
+    if (!P || group < 0 || group >= LUDWIG_HALO_GROUPS) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    LW_HIP(hipSetDevice(P->L->device));
+    ++P->L->version;
+    { const int r = before_external_write(P->L, field); if (r) return r; }
+    return halo_unpack_group(P, group, field, hip_stream ? (hipStream_t)hip_stream : P->L->stream);
+}
+
+int ludwig_halo_plan_buffers(const LudwigHaloPlan *P, int32_t group, void **send_dev, int64_t *n_send, void **recv_dev, int64_t *n_recv)
+{
+    if (!P || group < 0 || group >= LUDWIG_HALO_GROUPS) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    const LudwigHaloPlan::Group &G = P->g[group];
+    if (send_dev) *send_dev = G.send_buf;
+    if (n_send) *n_send = G.n_send;
+    if (recv_dev) *recv_dev = G.recv_buf;
+    if (n_recv) *n_recv = G.n_recv;
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, const int32_t *fields)
+{
+    if (!P || n < 0 || n > LUDWIG_HALO_GROUPS || (n > 0 && (!groups || !fields))) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    LudwigLevel *L = P->L;
+    LW_HIP(hipSetDevice(L->device));
+    for (int i = 0; i < n; ++i) {
+        if (groups[i] < 0 || groups[i] >= LUDWIG_HALO_GROUPS) return fail(LUDWIG_ERR_INVALID, "bad group %d", groups[i]);
+        const int r = halo_prepare_field(L, groups[i], fields[i]);     // may queue work on the level's stream: before the event below
+        if (r) return r;
+    }
+    ++L->version;
+    LW_HIP(hipEventRecord(P->ev_ready, L->stream));
+    LW_HIP(hipStreamWaitEvent(P->s_comm, P->ev_ready, 0));
+    const int slot = (int)(P->n_timed % TIMING_RING);
+    if (P->timing) LW_HIP(hipEventRecord(P->t0[slot], P->s_comm));
+    for (int i = 0; i < n; ++i) {
+        const int r = halo_pack_group(P, groups[i], fields[i], P->s_comm);
+        if (r) return r;
+    }
+    RcclApi *api = P->comm ? rccl() : nullptr;
+    bool any_remote = false;
+    for (size_t p = 0; p < P->peers.size(); ++p)
+        if (P->comm && (P->peers[p] != P->comm->rank || P->self_via_rccl)) any_remote = true;
+    if (any_remote && !api) return fail(LUDWIG_ERR_STATE, "RCCL unavailable");
+    if (any_remote) LW_NCCL(api, api->GroupStart());
+    for (size_t p = 0; p < P->peers.size(); ++p) {
+        const bool self = !P->comm || (P->peers[p] == P->comm->rank && !P->self_via_rccl);
+        for (int i = 0; i < n; ++i) {
+            LudwigHaloPlan::Group &G = P->g[groups[i]];
+            const int64_t s0 = G.send_off[p], ns = G.send_off[p + 1] - s0, r0 = G.recv_off[p], nr = G.recv_off[p + 1] - r0;
+            if (self) {
+                if (ns != nr) return fail(LUDWIG_ERR_INVALID, "peer %zu is this rank itself but sends %lld and receives %lld elements", p, (long long)ns, (long long)nr);
+                if (ns) LW_HIP(hipMemcpyAsync(G.recv_buf + r0, G.send_buf + s0, (size_t)ns * 4, hipMemcpyDeviceToDevice, P->s_comm));
+            } else {
+                if (ns) LW_NCCL(api, api->Send(G.send_buf + s0, (size_t)ns, ncclFloat, P->peers[p], P->comm->comm, P->s_comm));
+                if (nr) LW_NCCL(api, api->Recv(G.recv_buf + r0, (size_t)nr, ncclFloat, P->peers[p], P->comm->comm, P->s_comm));
+            }
+        }
+    }
+    if (any_remote) LW_NCCL(api, api->GroupEnd());
+    for (int i = 0; i < n; ++i) {
+        const int r = halo_unpack_group(P, groups[i], fields[i], P->s_comm);
+        if (r) return r;
+    }
+    if (P->timing) { LW_HIP(hipEventRecord(P->t1[slot], P->s_comm)); ++P->n_timed; }
+    LW_HIP(hipEventRecord(P->ev_done, P->s_comm));
+    P->pending = true;
+    return LUDWIG_OK;
+}
+
+int ludwig_halo_wait(LudwigHaloPlan *P)
+{
+    if (!P) return fail(LUDWIG_ERR_INVALID, "null plan");
+    if (!P->pending) return LUDWIG_OK;
+    LW_HIP(hipSetDevice(P->L->device));
+    LW_HIP(hipStreamWaitEvent(P->L->stream, P->ev_done, 0));
+    P->pending = false;
+    return LUDWIG_OK;
+}
+
+int ludwig_step_distributed(LudwigLevel *L, LudwigHaloPlan *P, const LudwigLevel *parent, int64_t t_sub, float u_curr, float parent_tau,
+                            float temporal_weight, const LudwigStepFlags *fl)
+{
+    if (!L || !P || !fl || P->L != L) return fail(LUDWIG_ERR_INVALID, "bad argument (the plan must belong to the level)");
+    int rc;
+    // interior blocks read and write owned cells only: they run while the ghosts of their input are still arriving
+    if ((rc = launch_stream_collide(L, parent, t_sub, u_curr, parent_tau, temporal_weight, fl, LUDWIG_PART_INTERIOR))) return rc;
+    if ((rc = ludwig_halo_wait(P))) return rc;
+    if ((rc = launch_stream_collide(L, parent, t_sub, u_curr, parent_tau, temporal_weight, fl, LUDWIG_PART_BOUNDARY))) return rc;
+    if (L->has_post) {
+        // the correction rewrites f_out from post-collision values of neighbour cells (src/bouzidi_kernel.jl:44-77): the few that
+        // live across a cut are fetched in between, and waited for
+        if (P->g[2].n_send || P->g[2].n_recv) {
+            const int32_t grp = 2, fld = LUDWIG_F_POST;
+            if ((rc = ludwig_halo_exchange(P, 1, &grp, &fld))) return rc;
+            if ((rc = ludwig_halo_wait(P))) return rc;
+        }
+        if ((rc = launch_bouzidi(L, t_sub, fl->q_min_threshold))) return rc;
+    }
+    const bool out_temp = t_sub % 2 == 0;                    // reference src/solver_control.jl:35-41
+    const int32_t grps[2] = {0, 1}, flds[2] = {out_temp ? LUDWIG_F_TEMP : LUDWIG_F, out_temp ? LUDWIG_VEL_TEMP : LUDWIG_VEL};
+    return ludwig_halo_exchange(P, 2, grps, flds);           // left in flight: the next call's interior blocks run under it
 }
 
 }  // extern "C"

@@ -106,7 +106,6 @@ def main():
         rep["skipped"] = sorted(skip)
     rep["peers"] = len(plan.peers)
     rep["view_blocks"] = int(view.level.n_blocks)
-    rep["stride_blocks"] = runner.level.population_stride() // 512
     rep["halo_bytes_per_step"] = plan.bytes_per_step()
     # ghosts of the start state: sin(x + one period) is not bit-equal to sin(x) in floating point, so fetch them the same way
     runner.ex.exchange("f", "vel")

@@ -379,8 +379,16 @@ def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
     assert sorted(order) == list(range(grids[0].n_blocks)) and not np.array_equal(order, np.arange(grids[0].n_blocks))
     inv = np.argsort(order)                                          # internal position -> reference block
     patch_ref = f_new[..., 5] * np.float32(1.01)                     # (8,8,8,nb) in the reference order
-    patch = np.ascontiguousarray(patch_ref[:, :, :, inv].reshape(-1, order="F"))
-    assert hip.hipMemcpy(C.c_void_p(ptr + 5 * dev[0].population_stride() * 4), patch.ctypes.data, patch.nbytes, 1) == 0   # host -> device
+    # the device array is block-major, [internal block][27][512] (ludwig_level_field_layout): population 5 of every block
+    K, block_stride, comp_stride = dev[0].field_layout("f")
+    assert (K, block_stride, comp_stride) == (27, 27 * 512, 512)
+    nb0 = grids[0].n_blocks
+    raw = np.empty(nb0 * block_stride, dtype=np.float32)
+    assert hip.hipMemcpy(raw.ctypes.data, C.c_void_p(ptr), raw.nbytes, 2) == 0          # device -> host
+    raw3 = raw.reshape(nb0, 27, 512)
+    assert np.array_equal(raw3[:, 7, :], f_new[..., 7].reshape(512, nb0, order="F").T[inv])      # the layout is as documented
+    raw3[:, 5, :] = patch_ref.reshape(512, nb0, order="F").T[inv]
+    assert hip.hipMemcpy(C.c_void_p(ptr), raw.ctypes.data, raw.nbytes, 1) == 0          # host -> device
     perform_timestep_v2(dev[1], dev[0], dev[0].tau, u, params, 2 * t + 1, np.float32(0.5))
     got, got_old = dev[1].download("f"), dev[0].download("f_old")
 
@@ -490,21 +498,22 @@ def test_stepping_stream_with_reserved_compute_units(gpu):
     _lib.check(lib.ludwig_stream_destroy(0, plain))
 
 
-@pytest.mark.parametrize("pad", ["3", "40"])
-def test_padded_population_stride_gives_the_same_bits(gpu, monkeypatch, pad):
-    """The device arrays may keep more than 512 n_blocks elements between two populations (ludwig_level_population_stride; the
-    library pads n_blocks off the distances that load MI355X's memory channels unevenly). Everything that crosses the ABI keeps
-    the reference's stride: a 3-level wall-model tunnel with Bouzidi cells stepped with a forced padding (every array, the q map,
-    the parents' interpolation reads, upload / download) equals the oracle bit for bit; halo pack / unpack address the same cells."""
+@pytest.mark.parametrize("wide", [False, True])
+def test_block_major_storage_is_invisible_at_the_abi(gpu, monkeypatch, wide):
+    """The device arrays are block-major (ludwig_level_field_layout); everything that crosses the ABI keeps the reference's
+    [8,8,8,n_blocks,K]. A 3-level wall-model tunnel with Bouzidi cells (every array, the q map, the parents' interpolation reads,
+    upload / download) equals the oracle bit for bit, with 32-bit per-lane offsets and with the 64-bit addresses levels of 4 GiB and
+    more use (forced here: LUDWIG_WIDE_ADDR); halo pack / unpack, given element offsets of the reference layout, address the same cells."""
     import ctypes as C
     import torch
     from open_ludwig_amd import _lib
-    monkeypatch.setenv("LUDWIG_STRIDE_PAD_BLOCKS", pad)
+    if wide:
+        monkeypatch.setenv("LUDWIG_WIDE_ADDR", "1")
     grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)
     dev = run_both(grids, params, 4, 0.05, batch=3)
-    for g, d in zip(grids, dev):
-        assert d.population_stride() == 512 * (g.n_blocks + int(pad))
-        assert d.field_ptr("vel")[1] == 3 * 4 * d.population_stride()
+    for d in dev:
+        assert d.field_layout("vel") == (3, 3 * 512, 512) and d.field_layout("rho") == (1, 512, 512)
+        assert d.field_ptr("vel")[1] == 3 * 4 * 512 * d.n_blocks
     # pack / unpack take element offsets of the REFERENCE layout: pick population 5 of 100 cells scattered over level 2
     d, g = dev[1], grids[1]
     fn, _ = oracle.newest_buffers(1, 4)

@@ -1,8 +1,7 @@
-"""Step time of the REAL stepping kernel against the distance between two populations in device memory.
-The library pads the population stride internally (ludwig_level_population_stride); LUDWIG_STRIDE_PAD_BLOCKS=k overrides its rule,
-so one host level is uploaded again and again with another k. usage: stride_padding.py [--nb NBX NBY NBZ] [--rule] [k ...]
-  --rule : leave the choice to the library (no override) and print what it chose.
-tools/stridebench.hip sweeps the same distance with a math-free emulation in seconds; this script confirms its picks."""
+"""Per-cell stepping rate of the REAL kernel against the block count of the level. With the reference's population-major arrays the
+distance between two populations is n_blocks x 2 KiB, and the step lost 5-30 % at some distances (64.5, 65.75, 68, 76-77 ... MiB:
+profiles/r02_population_stride_sweep.txt, profiles/r03_stride_sweep_emulation.txt). The device arrays are block-major since round 3:
+the rate must no longer depend on n_blocks. usage: stride_padding.py [NBXxNBYxNBZ ...]   (periodic boxes, blocks per axis)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,24 +9,14 @@ import numpy as np, torch
 from open_ludwig_amd import adapt, cases
 from open_ludwig_amd.physics import stream_collide
 
-args = sys.argv[1:]
-nb = (32, 32, 32)
-if "--nb" in args:
-    i = args.index("--nb")
-    nb = tuple(int(v) for v in args[i + 1:i + 4])
-    del args[i:i + 4]
-rule = "--rule" in args
-args = [a for a in args if a != "--rule"]
-pads = [int(v) for v in args] or ([None] if rule else [0, 512, 2048, 2560, 0])
-grids, params = cases.periodic_box(nb, upload_only=True)
-n_blocks = grids[0].n_blocks
-cells = n_blocks * 512
-for k in pads:
-    if k is None:
-        os.environ.pop("LUDWIG_STRIDE_PAD_BLOCKS", None)
-    else:
-        os.environ["LUDWIG_STRIDE_PAD_BLOCKS"] = str(k)
+# 32768 = the headline box; 33024 = 64.5 MiB, 33792 = 66, 34816 = 68, 39424 = 77, 42496 = 83, 46080 = 90 MiB (the old bad distances)
+boxes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or \
+        [(32, 32, 32), (32, 24, 43), (32, 32, 33), (32, 32, 34), (32, 28, 44), (32, 32, 32), (32, 32, 41), (32, 36, 40), (32, 32, 32)]
+for nb in boxes:
+    grids, params = cases.periodic_box(nb, upload_only=True)
+    cells = grids[0].n_blocks * 512
     d = adapt(grids[0], 0)
+    del grids
     t = 1
     for _ in range(40):
         stream_collide(d, None, np.float32(0.5), np.float32(0.0), params, t); t += 1
@@ -35,7 +24,6 @@ for k in pads:
     for _ in range(150):
         stream_collide(d, None, np.float32(0.5), np.float32(0.0), params, t); t += 1
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 150 * 1e3
-    sk = d.population_stride()
-    print(f"{n_blocks} blocks, pad {'rule' if k is None else k}: stride {sk // 512} blocks = {sk * 4 / 2**20:.3f} MiB: {ms:.4f} ms per step, "
+    print(f"{nb[0]}x{nb[1]}x{nb[2]} = {cells // 512} blocks ({cells // 512 / 512:.3f} MiB per population in the reference layout): {ms:.4f} ms per step, "
           f"{cells / ms / 1e3:.0f} MLUPS", flush=True)
     d.close(); del d

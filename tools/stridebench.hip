@@ -10,6 +10,7 @@
 //   mode 0: f_in and f_out both with stride S, f_out placed `gap` blocks (default: 27 S rounded to 2 MiB) behind f_in.
 //   mode 1: loads only; mode 2: stores only (which side the bad distances hurt).
 //   mode 3 / 4: BLOCK-major storage f[block][k][512] with 32-bit / 64-bit per-lane addresses (no stride at all).
+//   mode 5 / 6: the same with the planes outermost inside a block, f[block][z][k][64].
 // Output: one line per S: blocks, MiB, ms per launch.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void k_move(const float *__restrict__ fin, flo
 
 // Block-major storage: f[block][k][512], vel[block][c][512] - the 27 populations of a block are contiguous (54 KiB), so there is no
 // distance between populations to get wrong. WIDE: 64-bit per-lane addresses (what a level above 77 672 blocks - 4 GiB of f - needs).
-template <bool WIDE>
+template <bool WIDE, bool PLANE = false>
 __global__ __launch_bounds__(256) void k_move_bm(const float *__restrict__ fin, float *__restrict__ fout, const float *__restrict__ vin,
                                                  float *__restrict__ vout, int NB)
 {
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(256) void k_move_bm(const float *__restrict__ fin, 
     // still forces the address through vector registers
     const int sel_own = (lane == 63 && NB < 0) ? bup : b;   // NB < 0 never holds: a per-lane value the compiler cannot fold
     float v[Q], u[3];
+    // PLANE: plane-major inside the block, f[block][z][k][64]: the 27 planes a wave stores are one contiguous 6.75 KiB piece
     auto addr = [&](const float *base, int blk, uint32_t comps, uint32_t inner) -> const float * {
+        if (PLANE) { const uint32_t k = inner >> 11, zz = (inner >> 8) & 7, l4 = inner & 255; inner = zz * (comps * 256u) + k * 256u + l4; }
         if (WIDE) return (const float *)((const char *)base + (uint64_t)(uint32_t)blk * (uint64_t)(comps * 2048u) + inner);
         return (const float *)((const char *)base + (uint32_t)((uint32_t)blk * (comps * 2048u) + inner));
     };
@@ -120,13 +123,15 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const dim3 grid((unsigned)(nblk / 4 * 8)), block(256);
     printf("# NB %d (%ld blocks), mode %d, reps %d; stride from %ld to %ld step %ld blocks\n", NB, nblk, mode, reps, from, to, step);
-    if (mode == 3 || mode == 4) {          // block-major storage, 32-bit / 64-bit per-lane addresses: one line, no stride to sweep
+    if (mode >= 3 && mode <= 6) {          // block-major storage, 32-bit / 64-bit per-lane addresses: one line, no stride to sweep
         float *fin = (float *)buf, *fout = (float *)(buf + (((size_t)nblk * 512 * Q * 4 + ((size_t)2 << 20) - 1) >> 21 << 21));
-        if (mode == 3 && (size_t)nblk * 55296 >= ((size_t)1 << 32)) { printf("mode 3 needs < 77672 blocks\n"); return 1; }
+        if ((mode == 3 || mode == 5) && (size_t)nblk * 55296 >= ((size_t)1 << 32)) { printf("mode 3 needs < 77672 blocks\n"); return 1; }
         for (int rep = 0; rep < 5; ++rep) {
             auto launch = [&]() {
-                if (mode == 3) hipLaunchKernelGGL(k_move_bm<false>, grid, block, 0, 0, fin, fout, vin, vout, NB);
-                else hipLaunchKernelGGL(k_move_bm<true>, grid, block, 0, 0, fin, fout, vin, vout, NB);
+                if (mode == 3) hipLaunchKernelGGL((k_move_bm<false, false>), grid, block, 0, 0, fin, fout, vin, vout, NB);
+                else if (mode == 4) hipLaunchKernelGGL((k_move_bm<true, false>), grid, block, 0, 0, fin, fout, vin, vout, NB);
+                else if (mode == 5) hipLaunchKernelGGL((k_move_bm<false, true>), grid, block, 0, 0, fin, fout, vin, vout, NB);
+                else hipLaunchKernelGGL((k_move_bm<true, true>), grid, block, 0, 0, fin, fout, vin, vout, NB);
             };
             for (int i = 0; i < 3; ++i) launch();
             CK(hipEventRecord(e0, 0));
@@ -135,7 +140,7 @@ int main(int argc, char **argv)
             CK(hipEventSynchronize(e1));
             float ms = 0.f;
             CK(hipEventElapsedTime(&ms, e0, e1));
-            printf("block-major %s %.4f\n", mode == 3 ? "32-bit" : "64-bit", ms / reps);
+            printf("%s %s %.4f\n", mode <= 4 ? "block-major" : "plane-major", (mode & 1) ? "32-bit" : "64-bit", ms / reps);
         }
         return 0;
     }
