@@ -356,9 +356,11 @@ def main():
                 "halo_bytes_per_rank_per_step": runner.ex.plan.bytes_per_step(), "peers_of_rank0": len([p for p in runner.ex.plan.peers if p != rank]),
                 "exchange_ms_mean_max_over_ranks": round(float(x[0].item()), 4), "exchange_ms_worst": round(float(x[1].item()), 4),
                 "overlap": not args.no_overlap, "compute_units_left_to_the_exchange": runner.reserved_cus,
-                "note": "exchange = pack -> grouped isend/irecv -> unpack on a high-priority comm stream, timed with events on that stream "
-                        "(the span includes waiting beside the interior launch it runs under); enqueued after the next step's interior launch; "
-                        "RCCL on a high-priority stream; schedule verified over RCCL on one GPU by tests/test_rccl_loopback.py"}
+                "transport": ("librccl called from libludwig_hip.so (ludwig_step_distributed: ncclSend / ncclRecv per peer in one group)"
+                              if runner.transport == "native" else "torch.distributed batch_isend_irecv from Python" + (" over gloo, host-staged" if rehearsal else "")),
+                "note": "exchange = pack -> grouped send/recv -> unpack on a high-priority stream of its own, timed with events on that stream "
+                        "(the span includes waiting beside the interior launch it runs under); queued at the end of the step that produced the "
+                        "data, joined before the next step's boundary blocks; schedule verified over RCCL on one GPU by tests/test_rccl_loopback.py"}
 
     if rank == 0:
         total_cells = cells_per_rank * world

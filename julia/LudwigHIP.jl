@@ -115,6 +115,68 @@ function stream_create(device::Integer, reserved_cus::Integer)
 end
 stream_destroy(device::Integer, s::Ptr{Cvoid}) = check(ccall((:ludwig_stream_destroy, LIB), Cint, (Cint, Ptr{Cvoid}), Cint(device), s))
 
+# ---- multi-GPU (no counterpart in the reference: single device, src/main.jl:75). One Julia process per GPU; the host carries the
+# 128-byte RCCL id from rank 0 to the others by whatever it already has (MPI.jl: MPI.Bcast!, a shared file, Sockets). ----
+struct Comm
+    handle::Ptr{Cvoid}
+end
+"""ncclGetUniqueId through the library: call on ONE rank, broadcast the 128 bytes."""
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    GC.@preserve id check(ccall((:ludwig_comm_unique_id, LIB), Cint, (Ptr{Cvoid},), pointer(id)))
+    return id
+end
+function Comm(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve id check(ccall((:ludwig_comm_create, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}), pointer(id), Cint(rank), Cint(world), Cint(device), out))
+    return Comm(out[])
+end
+destroy!(c::Comm) = ccall((:ludwig_comm_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.handle)
+"""in-place all-reduce of a few Float32 diagnostics (op 0 sum, 2 max, 3 min): rho_min, the nine force sums"""
+allreduce!(c::Comm, v::Vector{Float32}, op::Integer) =
+    GC.@preserve v check(ccall((:ludwig_comm_allreduce_f32, LIB), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int32), c.handle, pointer(v), Int32(length(v)), Int32(op)))
+
+"""LudwigHaloPlanDesc (include/ludwig_hip.h): per group g = 1..4 (populations, velocity, f_post_collision, rho) the element offsets
+this rank sends / receives, all peers concatenated; offsets are 0-based positions in the level's arrays as the reference lays them out."""
+struct HaloPlanDesc
+    n_peers::Int32
+    peer_ranks::Ptr{Int32}
+    send_count::NTuple{4,Ptr{Int64}}
+    recv_count::NTuple{4,Ptr{Int64}}
+    send_index::NTuple{4,Ptr{Int64}}
+    recv_index::NTuple{4,Ptr{Int64}}
+end
+struct HaloPlan
+    handle::Ptr{Cvoid}
+end
+function HaloPlan(d::DeviceLevel, c::Union{Comm,Nothing}, peers::Vector{Int32}, send_count::NTuple{4,Vector{Int64}}, recv_count::NTuple{4,Vector{Int64}},
+                  send_index::NTuple{4,Vector{Int64}}, recv_index::NTuple{4,Vector{Int64}})
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve peers send_count recv_count send_index recv_index begin
+        desc = HaloPlanDesc(Int32(length(peers)), pointer(peers), map(pointer, send_count), map(pointer, recv_count), map(pointer, send_index), map(pointer, recv_index))
+        check(ccall((:ludwig_halo_plan_create, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{HaloPlanDesc}, Ref{Ptr{Cvoid}}),
+                    d.handle, c === nothing ? C_NULL : c.handle, desc, out))
+    end
+    return HaloPlan(out[])
+end
+destroy!(p::HaloPlan) = ccall((:ludwig_halo_plan_destroy, LIB), Cvoid, (Ptr{Cvoid},), p.handle)
+"""one exchange, queued behind what the level's stream holds: group groups[i] (0-based) moves field fields[i]"""
+exchange!(p::HaloPlan, groups::Vector{Int32}, fields::Vector{Int32}) =
+    GC.@preserve groups fields check(ccall((:ludwig_halo_exchange, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}), p.handle, Int32(length(groups)), pointer(groups), pointer(fields)))
+wait!(p::HaloPlan) = check(ccall((:ludwig_halo_wait, LIB), Cint, (Ptr{Cvoid},), p.handle))
+
+"""
+perform_timestep_v2! of a level spread over ranks: interior blocks, wait for the previous exchange, boundary blocks, [f_post halo,
+Bouzidi], this step's exchange left in flight (ludwig_step_distributed). Drop-in for `perform_timestep!` in `recursive_step!` below
+when the level has a plan.
+"""
+function perform_timestep_distributed!(d::DeviceLevel, plan::HaloPlan, parent::Union{DeviceLevel,Nothing}, parent_tau::Float32, u_curr::Float32,
+                                       flags::StepFlags, timestep::Integer, temporal_weight::Float32)
+    p = parent === nothing ? C_NULL : parent.handle
+    check(ccall((:ludwig_step_distributed, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cfloat, Cfloat, Cfloat, Ref{StepFlags}),
+                d.handle, plan.handle, p, Int64(timestep), u_curr, parent_tau, temporal_weight, flags))
+end
+
 """
 recursive_step! with the device calls swapped (src/solver_control.jl:21-143): same order, same parity, same weights.
 """

@@ -30,7 +30,13 @@ EXPORTED_SYMBOLS = [
     "ludwig_save_old", "ludwig_execute_timestep_batch", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
     "ludwig_map_surface_stresses", "ludwig_level_rho_min", "ludwig_level_block_order",
     "ludwig_stream_create", "ludwig_stream_destroy", "ludwig_level_field_layout", "ludwig_level_set_rho_store",
+    "ludwig_comm_unique_id", "ludwig_comm_create", "ludwig_comm_destroy", "ludwig_comm_allreduce_f32",
+    "ludwig_halo_plan_create", "ludwig_halo_plan_destroy", "ludwig_halo_exchange", "ludwig_halo_wait",
+    "ludwig_halo_plan_pack", "ludwig_halo_plan_unpack", "ludwig_halo_plan_buffers", "ludwig_halo_plan_timing",
+    "ludwig_halo_plan_exchange_ms", "ludwig_step_distributed",
 ]
+UNIQUE_ID_BYTES = 128
+HALO_GROUPS = ("f", "vel", "f_post", "rho")      # group index of partition.FIELD_GROUPS in a LudwigHaloPlanDesc
 
 
 class LudwigError(RuntimeError):
@@ -67,6 +73,14 @@ class SurfaceParams(C.Structure):
     _fields_ = [
         ("dx", C.c_float), ("tau", C.c_float), ("offset_x", C.c_float), ("offset_y", C.c_float), ("offset_z", C.c_float),
         ("pressure_scale", C.c_float), ("stress_scale", C.c_float), ("search_radius", C.c_int32),
+    ]
+
+
+class HaloPlanDesc(C.Structure):
+    _fields_ = [
+        ("n_peers", C.c_int32), ("peer_ranks", C.c_void_p),
+        ("send_count", C.c_void_p * 4), ("recv_count", C.c_void_p * 4),
+        ("send_index", C.c_void_p * 4), ("recv_index", C.c_void_p * 4),
     ]
 
 
@@ -120,6 +134,20 @@ def load() -> C.CDLL:
         "ludwig_stream_destroy": (C.c_int, [i32, vp]),
         "ludwig_level_field_layout": (C.c_int, [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
         "ludwig_level_set_rho_store": (C.c_int, [vp, i32]),
+        "ludwig_comm_unique_id": (C.c_int, [vp]),
+        "ludwig_comm_create": (C.c_int, [vp, i32, i32, i32, C.POINTER(vp)]),
+        "ludwig_comm_destroy": (None, [vp]),
+        "ludwig_comm_allreduce_f32": (C.c_int, [vp, vp, i32, i32]),
+        "ludwig_halo_plan_create": (C.c_int, [vp, vp, C.POINTER(HaloPlanDesc), C.POINTER(vp)]),
+        "ludwig_halo_plan_destroy": (None, [vp]),
+        "ludwig_halo_exchange": (C.c_int, [vp, i32, vp, vp]),
+        "ludwig_halo_wait": (C.c_int, [vp]),
+        "ludwig_halo_plan_pack": (C.c_int, [vp, i32, i32, vp]),
+        "ludwig_halo_plan_unpack": (C.c_int, [vp, i32, i32, vp]),
+        "ludwig_halo_plan_buffers": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)]),
+        "ludwig_halo_plan_timing": (C.c_int, [vp, i32]),
+        "ludwig_halo_plan_exchange_ms": (C.c_int, [vp, vp, i32, C.POINTER(C.c_int32)]),
+        "ludwig_step_distributed": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, C.POINTER(StepFlags)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export what the header declares

@@ -78,7 +78,8 @@ class DistributedStepper:
         different summation order (observed <= 1e-6 relative) - bit-equality with one device is traded for not moving fields.
     `field()` still assembles a GLOBAL array, on rank 0 only; it is used on VTU output steps."""
 
-    def __init__(self, host_grids, device: Optional[int] = None, owners=None, stage_through_host: bool = False):
+    def __init__(self, host_grids, device: Optional[int] = None, owners=None, stage_through_host: bool = False,
+                 overlap: Optional[bool] = None, transport: Optional[str] = None):
         import torch
         import torch.distributed as dist
         from . import partition
@@ -89,11 +90,17 @@ class DistributedStepper:
         torch.cuda.set_device(self.device)
         self.owners = owners if owners is not None else partition.level_owners(host_grids, self.world)
         self.stage = stage_through_host
+        # overlap: each level's exchange runs under the part of its blocks that reads no ghost (partition.MultiLevelRunner);
+        # LUDWIG_NO_OVERLAP=1 (or overlap=False) falls back to step -> exchange -> wait, level by level. transport: "native" = RCCL
+        # called from the library (default with the nccl backend), "torch" = torch.distributed from Python (the gloo rehearsals).
+        self.overlap = (os.environ.get("LUDWIG_NO_OVERLAP") is None) if overlap is None else bool(overlap)
+        self.transport = transport
         self.runner = None
         self._tri = {}                         # level -> static triangle map (see surface_forces)
 
     def _start(self, params) -> None:
-        self.runner = self.partition.MultiLevelRunner(self.host, self.owners, params, self.rank, self.world, self.device, self.stage)
+        self.runner = self.partition.MultiLevelRunner(self.host, self.owners, params, self.rank, self.world, self.device, self.stage,
+                                                      overlap=self.overlap, transport=self.transport)
         for lv in self.runner.levels:
             if lv is not None:
                 lv.init_equilibrium()          # src/main.jl:126-135 (ghost blocks included: same rest state everywhere)
@@ -193,9 +200,7 @@ class DistributedStepper:
 
     def close(self):
         if self.runner is not None:
-            for lv in self.runner.levels:
-                if lv is not None:
-                    lv.close()
+            self.runner.close()          # plans, communicator, levels; the views and plans stay readable (statistics)
 
 
 def _aerodynamics(st, grids, mesh, params, symmetric: bool, rho_f=None, want_maps: bool = False):

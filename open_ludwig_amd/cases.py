@@ -120,12 +120,17 @@ def init_perturbed(level: BlockLevel, seed: int, u_mean: float = 0.04, amp: floa
 # ----------------------------------------------------------------------------------------------------------------
 # geometry: analytic sphere (stands in for voxelize_blocks!/flood fill/compute_bouzidi_qmap_sparse of row N1)
 # ----------------------------------------------------------------------------------------------------------------
-def add_sphere(level: BlockLevel, center, radius: float, *, bouzidi: bool = True, wall_dist: bool = True) -> None:
+def add_sphere(level: BlockLevel, center, radius: float, *, bouzidi: bool = True, wall_dist: bool = True, period=None,
+               list_blocks: Optional[int] = None) -> None:
     """Mark cells whose centre lies inside the sphere as obstacle; optionally fill the wall-distance field and build a
     Bouzidi q-map (Float16) + sparse boundary-cell list with the list semantics of src/bouzidi_setup.jl:115-143
-    (every cell, solid ones included, one of whose 26 links crosses the surface within the link length)."""
+    (every cell, solid ones included, one of whose 26 links crosses the surface within the link length).
+    period (cells per axis): a lattice of spheres, one per period (multi-GPU loop-back tests: every brick holds the same body);
+    list_blocks: only cells of the first so many blocks enter the Bouzidi list (the owned blocks of a rank's view)."""
     gx, gy, gz = global_cell_coords(level)
     px, py, pz = gx - 0.5 - center[0], gy - 0.5 - center[1], gz - 0.5 - center[2]
+    if period is not None:
+        px, py, pz = [(q + 0.5 * L) % L - 0.5 * L for q, L in zip((px, py, pz), period)]
     r = np.sqrt(px * px + py * py + pz * pz)
     level.obstacle[...] = r < radius
     if wall_dist:
@@ -155,6 +160,8 @@ def add_sphere(level: BlockLevel, center, radius: float, *, bouzidi: bool = True
         hit = ok & (t > 1e-9) & (t <= 1.0)
         q_map[..., k][hit] = t[hit].astype(np.float16)     # single rounding Float64 -> Float16 (src/bouzidi_setup.jl:128)
         any_hit |= hit
+    if list_blocks is not None:
+        any_hit[:, :, :, list_blocks:] = False
     idx = np.argwhere(any_hit)          # rows (x,y,z,b), 0-based
     order = np.lexsort((idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]))
     idx = idx[order]

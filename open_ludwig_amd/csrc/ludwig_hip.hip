@@ -38,6 +38,9 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 1 = blocks with a missing neighbour (GENERAL instantiation), 2 = all-neighbour blocks; 0 unused
+#ifndef LW_DEFAULT_SPLIT_STEP
+#define LW_DEFAULT_SPLIT_STEP 0
+#endif
 constexpr int XRUN = 4, XRUN_MAX = 4;       // waves per workgroup = blocks of an x-run (8 and 16 were tried in rounds 1-2: slower)
 
 }  // namespace
@@ -94,6 +97,11 @@ struct LudwigLevel {
     std::vector<uint8_t> h_comm_boundary;
     int32_t *items[N_PARTS][N_CLASSES] = {};
     int64_t n_items[N_PARTS][N_CLASSES] = {};
+    // small levels step both kinds of blocks in ONE launch (merge_classes): the all-neighbour workgroups followed by the general ones,
+    // through the GENERAL instantiation. The separate lists stay: a sub-step that has an interface pass to wait for steps the
+    // all-neighbour blocks first, under that pass (launch_stream_collide "split").
+    int32_t *items_merged[N_PARTS] = {};
+    int64_t n_items_merged[N_PARTS] = {};
     int n_fast_blocks = 0;
     bool general_in_runs[N_PARTS] = {};     // class-1 items are in x-run format (link bits, XRUN waves per workgroup)
     int64_t n_linked_items[N_PARTS] = {};   // class-2 waves that exchange a face column with a neighbouring wave
@@ -137,6 +145,9 @@ struct LudwigLevel {
     int64_t step_count = 0, last_step_t = -1, last_replay_step = -10;   // a level asked for rho after two steps in a row turns eager
     // ludwig_execute_timestep_batch runs every level on a stream of its own (level_streams below): events that order them
     hipStream_t own_stream = nullptr;
+    hipStream_t side_stream = nullptr;  // the interface pass of a split sub-step (same priority as own_stream)
+    hipEvent_t ev_fork = nullptr, ev_iface = nullptr;
+    hipEvent_t parent_wait = nullptr;   // set by recursive_step: the parent's step this sub-step's interface pass has to wait for
     hipEvent_t ev_stepped = nullptr;    // recorded on this level's stream after each of its steps (collision + Bouzidi)
     hipEvent_t ev_consumed = nullptr;   // recorded on the CHILD's stream once its interface pass has read this level's buffers
     bool ev_consumed_set = false;
@@ -338,12 +349,18 @@ int set_items(LudwigLevel *L, int part, const int32_t *items, int64_t n)
         for (int32_t it : cls[2])
             if (it >= 0 && (it & (ITEM_LINK_E | ITEM_LINK_W))) ++L->n_linked_items[part];
     }
+    std::vector<int32_t> merged;
     if (use_xrun && merge_classes(L, cls[1], cls[2])) {
         // one launch for the whole pass: the all-neighbour workgroups ride along in the GENERAL instantiation (its patch
         // phase finds nothing to do for them) - on small levels a launch boundary costs more than that
-        cls[2].insert(cls[2].end(), cls[1].begin(), cls[1].end());
-        cls[1].swap(cls[2]);
-        cls[2].clear();
+        merged = cls[2];
+        merged.insert(merged.end(), cls[1].begin(), cls[1].end());
+    }
+    if (L->items_merged[part]) { (void)hipFree(L->items_merged[part]); L->items_merged[part] = nullptr; }
+    L->n_items_merged[part] = (int64_t)merged.size();
+    if (!merged.empty()) {
+        LW_HIP(hipMalloc((void **)&L->items_merged[part], merged.size() * 4));
+        LW_HIP(hipMemcpy(L->items_merged[part], merged.data(), merged.size() * 4, hipMemcpyHostToDevice));
     }
     for (int c = 0; c < N_CLASSES; ++c) {
         bool any = false;
@@ -571,11 +588,16 @@ static void fill_parent_params(SCParams &p, const LudwigLevel *parent, int64_t t
     }
 }
 
-// Coarse -> fine interface pass for the general blocks of `part` (reference src/physics_kernels.jl:122-137): leaves p.f_iface
-// pointing at the values sub-step t_sub loads. ahead_of_step: called by interface_prepass, before the step's own launch.
-static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, SCParams &p, int64_t t_sub, float parent_tau,
-                          float temporal_weight, bool ahead_of_step)
+// Coarse -> fine interface pass for the general blocks of `part` (reference src/physics_kernels.jl:122-137), in two halves.
+// interface_decide: leaves p.f_iface pointing at the values sub-step t_sub loads and says whether kernels have to run for them
+// (IFACE_LAUNCH) or they exist already - produced ahead by interface_prepass (READY) or together with the previous sub-step's (HIT).
+// interface_launch: the two kernels on `st`. ahead_of_step: called by interface_prepass, before the step's own launch.
+enum IfaceState { IFACE_NONE, IFACE_READY, IFACE_HIT, IFACE_LAUNCH };
+
+static int interface_decide(LudwigLevel *L, const LudwigLevel *parent, int part, SCParams &p, int64_t t_sub, float parent_tau,
+                            float temporal_weight, bool ahead_of_step, IfaceState *state)
 {
+    *state = IFACE_NONE;
     if (!parent || L->n_items[part][1] == 0) return LUDWIG_OK;
     const int r = build_interface_links(L, parent, p.nx_g, p.ny_g, p.nz_g);
     if (r) return r;
@@ -586,16 +608,27 @@ static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, S
     const bool ready = pre.valid && pre.parent == parent && pre.parent_version == parent->version && pre.t_sub == t_sub &&
                        pre.tw == temporal_weight && pre.tau_parent == parent_tau && pre.use_temporal == p.use_temporal;
     pre.valid = ready && ahead_of_step;
+    *state = IFACE_READY;
     if (ready) return LUDWIG_OK;                 // produced by interface_prepass; the look-ahead record for t_sub + 1 stays as it is
     LudwigLevel::IfaceAhead &ah = L->ahead[part];
     const bool hit = ah.valid && ah.parent == parent && ah.parent_version == parent->version && ah.t_sub == t_sub &&
                      ah.tw == temporal_weight && ah.tau_parent == parent_tau && ah.use_temporal == p.use_temporal;
     if (hit && ahead_of_step) return LUDWIG_OK;  // nothing to do ahead: the step will find the values in f_iface2
     ah.valid = false;
+    *state = IFACE_HIT;
     if (hit) {
         p.f_iface = L->f_iface2;                 // computed together with the previous sub-step's values
         return LUDWIG_OK;
     }
+    *state = IFACE_LAUNCH;
+    return LUDWIG_OK;
+}
+
+static int interface_launch(LudwigLevel *L, const LudwigLevel *parent, int part, const SCParams &p, int64_t t_sub, float parent_tau,
+                            float temporal_weight, bool ahead_of_step, hipStream_t st)
+{
+    LudwigLevel::IfaceAhead &pre = L->prepared[part];
+    LudwigLevel::IfaceAhead &ah = L->ahead[part];
     // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
     const bool two = (t_sub % 2 == 0) && !parent->external_writer && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
     InterfaceArgs a{};
@@ -607,13 +640,13 @@ static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, S
     a.n_sources = L->n_sources[part]; a.n_links = L->n_links[part];
     const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
     if (two) {
-        hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, L->stream, p, a);
-        hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, L->stream, p, a);
+        hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, st, p, a);
+        hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, st, p, a);
         ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
         ah.tw = a.tw2; ah.tau_parent = parent_tau; ah.use_temporal = p.use_temporal;
     } else {
-        hipLaunchKernelGGL(k_interface_sources<false>, gs, dim3(256), 0, L->stream, p, a);
-        hipLaunchKernelGGL(k_interface_links<false>, gl, dim3(256), 0, L->stream, p, a);
+        hipLaunchKernelGGL(k_interface_sources<false>, gs, dim3(256), 0, st, p, a);
+        hipLaunchKernelGGL(k_interface_links<false>, gl, dim3(256), 0, st, p, a);
     }
     LW_HIP(hipGetLastError());
     if (ahead_of_step) {
@@ -623,10 +656,19 @@ static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, S
     // level streams (ludwig_execute_timestep_batch): the parent's buffers have been read - the last time for this
     // pair of sub-steps when the values for the second one were produced alongside
     if (parent->ev_consumed && L->own_stream && L->stream == L->own_stream) {
-        LW_HIP(hipEventRecord(parent->ev_consumed, L->stream));
+        LW_HIP(hipEventRecord(parent->ev_consumed, st));
         const_cast<LudwigLevel *>(parent)->ev_consumed_set = true;
     }
     return LUDWIG_OK;
+}
+
+static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, SCParams &p, int64_t t_sub, float parent_tau,
+                          float temporal_weight, bool ahead_of_step)
+{
+    IfaceState state;
+    const int r = interface_decide(L, parent, part, p, t_sub, parent_tau, temporal_weight, ahead_of_step, &state);
+    if (r || state != IFACE_LAUNCH) return r;
+    return interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, ahead_of_step, L->stream);
 }
 
 // The interface pass of sub-step t_sub, launched before the step itself. It reads the PARENT's buffers and writes this level's
@@ -715,16 +757,12 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     }
 
     const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
-    {
-        const int r = interface_pass(L, parent, part, p, t_sub, parent_tau, temporal_weight, false);
-        if (r) return r;
-    }
-    for (int c = 1; c < N_CLASSES; ++c) {
-        if (L->n_items[part][c] == 0) continue;
-        p.items = L->items[part][c];
-        const dim3 grid((unsigned)(L->n_items[part][c] / XRUN)), block(64 * XRUN);
-        const hipStream_t cs = L->stream;
-        const bool general = c == 1;
+    const hipStream_t cs = L->stream;
+    // one launch of a work list through the instantiation its blocks need
+    auto launch_list = [&](const int32_t *items, int64_t n_items, bool general) -> int {
+        if (n_items == 0) return LUDWIG_OK;
+        p.items = items;
+        const dim3 grid((unsigned)(n_items / XRUN)), block(64 * XRUN);
 #define LW_LAUNCH_X(G, P, W) do { if (L->wide) hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, G, P, W, false, true>), grid, block, 0, cs, p); \
             else hipLaunchKernelGGL((k_stream_collide_xrun<XRUN, G, P, W, false, false>), grid, block, 0, cs, p); } while (0)
         // WALL without POST goes through the <POST, WALL> instantiation (no block is flagged for the f_post store, so the null
@@ -741,6 +779,53 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         }
 #undef LW_LAUNCH_X
         LW_HIP(hipGetLastError());
+        return LUDWIG_OK;
+    };
+    const hipEvent_t parent_wait = L->parent_wait;          // level streams: the parent step this sub-step's interface values come from
+    L->parent_wait = nullptr;
+    IfaceState istate;
+    {
+        const int r = interface_decide(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, &istate);
+        if (r) return r;
+    }
+    // Split sub-step (level streams only; an experiment kept behind LUDWIG_SPLIT_STEP, default 0 = off). The interface pass is the one
+    // piece of a sub-step that reads the PARENT, and only the blocks with a missing neighbour read its result; the all-neighbour
+    // blocks depend on nothing but this level's previous sub-step. Mode 1: when the pass has to run (first sub-step of a pair), step the
+    // all-neighbour blocks FIRST - before this stream waits for the parent's step - then the wait, the pass and the general blocks.
+    // Mode 2: the pass on a side stream, under the all-neighbour blocks. Measured (profiles/r03_split_substep_ab.txt): mode 1 LOSES
+    // 1-6 % (two launches instead of the merged one cost more than the earlier start gains); mode 2 HALVES the speed of every
+    // multi-level case (3-level sphere 0.337 -> 0.665 ms per coarse step, wing 0.83 -> 1.08): HIP serves the streams of one priority from a
+    // small pool of hardware queues, the side stream lands in the queue of a level's own stream, and its wait for the parent then
+    // blocks that level's launches too (the lesson of round 2's RCCL traces, again).
+    static const int split_mode = [] { const char *e = getenv("LUDWIG_SPLIT_STEP"); return e ? atoi(e) : LW_DEFAULT_SPLIT_STEP; }();
+    const bool split = split_mode > 0 && istate == IFACE_LAUNCH && part == LUDWIG_PART_ALL && L->own_stream && L->stream == L->own_stream &&
+                       L->n_items[part][1] > 0 && L->n_items[part][2] > 0 && (split_mode == 1 || L->side_stream);
+    if (split && split_mode == 1) {
+        int r;
+        if ((r = launch_list(L->items[part][2], L->n_items[part][2], false))) return r;
+        if (parent_wait) LW_HIP(hipStreamWaitEvent(cs, parent_wait, 0));
+        if ((r = interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, cs))) return r;
+        if ((r = launch_list(L->items[part][1], L->n_items[part][1], true))) return r;
+    } else if (split) {
+        LW_HIP(hipEventRecord(L->ev_fork, cs));               // the pass rewrites side buffers the previous sub-step's launch read
+        LW_HIP(hipStreamWaitEvent(L->side_stream, L->ev_fork, 0));
+        if (parent_wait) LW_HIP(hipStreamWaitEvent(L->side_stream, parent_wait, 0));
+        int r = interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, L->side_stream);
+        if (r) return r;
+        LW_HIP(hipEventRecord(L->ev_iface, L->side_stream));
+        if ((r = launch_list(L->items[part][2], L->n_items[part][2], false))) return r;
+        LW_HIP(hipStreamWaitEvent(cs, L->ev_iface, 0));
+        if ((r = launch_list(L->items[part][1], L->n_items[part][1], true))) return r;
+    } else {
+        if (parent_wait) LW_HIP(hipStreamWaitEvent(cs, parent_wait, 0));
+        int r;
+        if (istate == IFACE_LAUNCH && (r = interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, cs))) return r;
+        if (L->n_items_merged[part] > 0) {
+            if ((r = launch_list(L->items_merged[part], L->n_items_merged[part], true))) return r;
+        } else {
+            if ((r = launch_list(L->items[part][1], L->n_items[part][1], true))) return r;
+            if ((r = launch_list(L->items[part][2], L->n_items[part][2], false))) return r;
+        }
     }
     if (!p.store_rho) {
         LudwigLevel::RhoReplay &rr = L->rho_replay[part];
@@ -879,6 +964,7 @@ void ludwig_level_destroy(LudwigLevel *L)
     for (int a = 0; a < N_PARTS; ++a) {
         for (int c = 0; c < N_CLASSES; ++c)
             if (L->items[a][c]) (void)hipFree(L->items[a][c]);
+        if (L->items_merged[a]) (void)hipFree(L->items_merged[a]);
         if (L->links[a]) (void)hipFree(L->links[a]);
         if (L->sources[a]) (void)hipFree(L->sources[a]);
         if (L->source_w[a]) (void)hipFree(L->source_w[a]);
@@ -889,6 +975,9 @@ void ludwig_level_destroy(LudwigLevel *L)
     if (L->d_ref2int) (void)hipFree(L->d_ref2int);
     if (L->scratch) (void)hipFree(L->scratch);
     if (L->own_stream) (void)hipStreamDestroy(L->own_stream);
+    if (L->side_stream) (void)hipStreamDestroy(L->side_stream);
+    if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
+    if (L->ev_iface) (void)hipEventDestroy(L->ev_iface);
     if (L->ev_stepped) (void)hipEventDestroy(L->ev_stepped);
     if (L->ev_consumed) (void)hipEventDestroy(L->ev_consumed);
     if (L->bouzidi_links) (void)hipFree(L->bouzidi_links);
@@ -1422,8 +1511,18 @@ static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-
     if (concurrent) {
         // every event operation costs the stream ~7 us between two kernels (kernel trace of the 3-level sphere): wait for a
         // parent step once, not once per sub-step
-        if (parent && (L->waited_parent != parent || L->waited_gen != parent->stepped_gen)) {
-            LW_HIP(hipStreamWaitEvent(L->stream, parent->ev_stepped, 0));
+        // the only reader of the parent is this level's interface pass: the wait for the parent's step goes where that pass goes
+        // (launch_stream_collide: this stream, or the side stream of a split sub-step) - unless the pass is hoisted below
+        const bool need_parent = parent && (L->waited_parent != parent || L->waited_gen != parent->stepped_gen);
+        bool hoisting = false;
+        if (has_children && L->ev_consumed_set) {
+            static const char *he0 = getenv("LUDWIG_IFACE_HOIST");
+            hoisting = he0 ? atoi(he0) != 0 : 20 * (int64_t)L->n_blocks >= 9 * (int64_t)levels[lvl]->n_blocks;
+        }
+        if (need_parent) {
+            // handed to launch_stream_collide, which waits where the interface pass goes (at once unless the sub-step is split)
+            if (hoisting) LW_HIP(hipStreamWaitEvent(L->stream, parent->ev_stepped, 0));
+            else L->parent_wait = parent->ev_stepped;
             L->waited_parent = parent; L->waited_gen = parent->stepped_gen;
         }
         if (has_children && L->ev_consumed_set) {
@@ -1467,30 +1566,55 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
     if (concurrent) {
         LW_HIP(hipSetDevice(levels[0]->device));
         LW_HIP(hipStreamSynchronize(user_stream));             // everything queued before the batch is done
+        // 1. every level gets its stream and its two events - or none does: a half-made set is destroyed again, so that a later
+        //    batch never finds a level with a stream but no events. The levels keep the caller's stream until all of it exists.
+        int pr_least = 0, pr_greatest = 0;
+        LW_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        const char *pe = getenv("LUDWIG_LEVEL_STREAM_PRIORITY");
+        const bool use_pr = !pe || atoi(pe) != 0;
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < n_levels && e == hipSuccess; ++i) {
+            LudwigLevel *L = levels[i];
+            const char *sse = getenv("LUDWIG_SPLIT_STEP");
+            const bool want_side = i > 0 && sse && atoi(sse) == 2;      // the side-stream experiment (launch_stream_collide "split")
+            if (L->own_stream && (L->side_stream || !want_side) && L->ev_stepped && L->ev_consumed && L->ev_fork && L->ev_iface) continue;
+            // the finest level is the critical chain (2^(n-1) sub-steps per coarse step): its stream gets the highest priority, the
+            // coarser levels fill what it leaves free (graded priorities: no better)
+            const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);
+            if (!L->own_stream) e = hipStreamCreateWithPriority(&L->own_stream, hipStreamNonBlocking, pr);
+            if (e == hipSuccess && !L->side_stream && want_side) e = hipStreamCreateWithPriority(&L->side_stream, hipStreamNonBlocking, pr);
+            if (e == hipSuccess && !L->ev_stepped) e = hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming);
+            if (e == hipSuccess && !L->ev_consumed) e = hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming);
+            if (e == hipSuccess && !L->ev_fork) e = hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming);
+            if (e == hipSuccess && !L->ev_iface) e = hipEventCreateWithFlags(&L->ev_iface, hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            for (int i = 0; i < n_levels; ++i) {
+                LudwigLevel *L = levels[i];
+                if (L->own_stream && L->ev_stepped && L->ev_consumed && L->ev_fork && L->ev_iface) continue;      // complete from an earlier batch: keep
+                hipEvent_t *evs[] = {&L->ev_stepped, &L->ev_consumed, &L->ev_fork, &L->ev_iface};
+                for (hipEvent_t *ev : evs)
+                    if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
+                if (L->side_stream) { (void)hipStreamDestroy(L->side_stream); L->side_stream = nullptr; }
+                if (L->own_stream) { (void)hipStreamDestroy(L->own_stream); L->own_stream = nullptr; }
+            }
+            return fail(LUDWIG_ERR_HIP, "batch: level streams: %s", hipGetErrorString(e));
+        }
+        // 2. switch over; one way back for every early return
+        auto restore = [&]() { for (int j = 0; j < n_levels; ++j) levels[j]->stream = user_stream; };
         for (int i = 0; i < n_levels; ++i) {
             LudwigLevel *L = levels[i];
-            if (!L->own_stream) {
-                // the finest level is the critical chain (2^(n-1) sub-steps per coarse step): its stream gets the highest priority, the
-                // coarser levels fill what it leaves free
-                int pr_least = 0, pr_greatest = 0;
-                LW_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-                const char *pe = getenv("LUDWIG_LEVEL_STREAM_PRIORITY");
-                const bool use_pr = !pe || atoi(pe) != 0;
-                const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);   // graded priorities: no better
-                LW_HIP(hipStreamCreateWithPriority(&L->own_stream, hipStreamNonBlocking, pr));
-                LW_HIP(hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming));
-                LW_HIP(hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming));
-            }
             L->ev_consumed_set = false;
             L->waited_parent = nullptr;
+            L->parent_wait = nullptr;
             L->stream = L->own_stream;
-            if (i + 1 < n_levels && !L->rho_eager) {            // children interpolate from rho after every step
+        }
+        for (int i = 0; i + 1 < n_levels; ++i) {
+            LudwigLevel *L = levels[i];
+            if (!L->rho_eager) {                               // children interpolate from rho after every step
                 L->rho_eager = true;
                 const int r = ensure_rho(L);
-                if (r) {
-                    for (int j = 0; j <= i; ++j) levels[j]->stream = user_stream;
-                    return r;
-                }
+                if (r) { restore(); return r; }
             }
         }
     }

@@ -374,6 +374,152 @@ class HaloExchanger:
         return out
 
 
+class NativeHalo:
+    """The halo exchange of one level behind the C ABI (include/ludwig_hip.h "multi-GPU"): the plan is translated and uploaded once
+    (ludwig_halo_plan_create), an exchange is one call - pack, one grouped ncclSend / ncclRecv per peer straight from RCCL, unpack, all
+    on the plan's own high-priority stream - and costs the host three kernel launches and a group call. `comm`: a handle from
+    native_comm(), or None when every peer is this rank itself (device copies). wire_rank: peer of the plan -> rank the message
+    really travels to (the loop-back test wires every peer to rank 0)."""
+
+    def __init__(self, plan: HaloPlan, level, comm, wire_rank: Optional[Dict[int, int]] = None):
+        import ctypes as C
+        from . import _lib
+        self._lib, self.C = _lib, C
+        self.plan, self.level, self.comm = plan, level, comm
+        lib = _lib.load()
+        n = len(plan.peers)
+        wire = wire_rank or {}
+        peers = np.asarray([wire.get(p, p) for p in plan.peers], dtype=np.int32)
+        d = _lib.HaloPlanDesc()
+        d.n_peers = n
+        d.peer_ranks = peers.ctypes.data
+        keep = [peers]
+        for gi, name in enumerate(FIELD_GROUPS):
+            sc = np.asarray([len(plan.send[p][name]) for p in plan.peers], dtype=np.int64)
+            rc = np.asarray([len(plan.recv[p][name]) for p in plan.peers], dtype=np.int64)
+            si = np.ascontiguousarray(np.concatenate([plan.send[p][name] for p in plan.peers]) if n else np.zeros(0), dtype=np.int64)
+            ri = np.ascontiguousarray(np.concatenate([plan.recv[p][name] for p in plan.peers]) if n else np.zeros(0), dtype=np.int64)
+            keep += [sc, rc, si, ri]
+            d.send_count[gi], d.recv_count[gi] = sc.ctypes.data, rc.ctypes.data
+            d.send_index[gi], d.recv_index[gi] = si.ctypes.data, ri.ctypes.data
+        h = C.c_void_p()
+        _lib.check(lib.ludwig_halo_plan_create(level.handle, comm, C.byref(d), C.byref(h)))
+        self._h = h
+        self._timing = False
+
+    @property
+    def handle(self):
+        return self._h
+
+    def post(self, fields: Dict[str, str]) -> None:
+        """queue one exchange behind everything queued on the level's stream so far; returns at once"""
+        C, _lib = self.C, self._lib
+        n = len(fields)
+        groups = (C.c_int32 * n)(*[FIELD_GROUPS.index(g) for g in fields])
+        flds = (C.c_int32 * n)(*[_lib.FIELD_NAMES[f] for f in fields.values()])
+        _lib.check(_lib.load().ludwig_halo_exchange(self._h, n, groups, flds))
+
+    def join(self) -> None:
+        """what is queued on the level's stream from here on runs after the last posted exchange"""
+        self._lib.check(self._lib.load().ludwig_halo_wait(self._h))
+
+    @property
+    def timing(self) -> bool:
+        return self._timing
+
+    @timing.setter
+    def timing(self, on: bool) -> None:
+        self._lib.check(self._lib.load().ludwig_halo_plan_timing(self._h, 1 if on else 0))
+        self._timing = bool(on)
+
+    def exchange_ms(self) -> List[float]:
+        C = self.C
+        out: List[float] = []
+        buf = (C.c_float * 256)()
+        n = C.c_int32(0)
+        while True:
+            self._lib.check(self._lib.load().ludwig_halo_plan_exchange_ms(self._h, buf, 256, C.byref(n)))
+            out += [float(buf[i]) for i in range(n.value)]
+            if n.value < 256:
+                return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.load().ludwig_halo_plan_destroy(self._h)
+            self._h = None
+
+
+class TorchHalo:
+    """The same post / join interface over torch.distributed (HaloExchanger): the transport of the one-GPU rehearsals (gloo with
+    host-staged messages; RCCL refuses two ranks on one device) and of the CPU tests."""
+
+    def __init__(self, ex: "HaloExchanger", s_comp, s_comm):
+        import torch
+        self.torch, self.ex, self.plan = torch, ex, ex.plan
+        self.s_comp, self.s_comm = s_comp, s_comm
+        self.ev_ready, self.ev_done = torch.cuda.Event(), torch.cuda.Event()
+        self.pending = False
+
+    def post(self, fields: Dict[str, str]) -> None:
+        if self.s_comm is self.s_comp:
+            self.ex.exchange_fields(fields)
+            return
+        self.ev_ready.record(self.s_comp)
+        with self.torch.cuda.stream(self.s_comm):
+            self.s_comm.wait_event(self.ev_ready)
+            self.ex.exchange_fields(fields)
+            self.ev_done.record(self.s_comm)
+        self.pending = True
+
+    def join(self) -> None:
+        if self.pending:
+            self.s_comp.wait_event(self.ev_done)
+            self.pending = False
+
+    @property
+    def timing(self) -> bool:
+        return self.ex.timing
+
+    @timing.setter
+    def timing(self, on: bool) -> None:
+        self.ex.timing = on
+
+    def exchange_ms(self) -> List[float]:
+        return self.ex.exchange_ms()
+
+    def close(self) -> None:
+        self.ex._events = []
+        self.ev_ready = self.ev_done = None
+
+
+def native_comm(device: int):
+    """A LudwigComm over the ranks of the default torch.distributed group: rank 0 draws the RCCL unique id (ludwig_comm_unique_id),
+    the 128 bytes travel through the process group the ranks already share, every rank joins (ludwig_comm_create). Returns the
+    handle (a ctypes.c_void_p); None when torch.distributed is not initialised (single process: every peer is this rank)."""
+    import ctypes as C
+    import torch.distributed as dist
+    from . import _lib
+    if not dist.is_initialized():
+        return None
+    lib = _lib.load()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [None]
+    if rank == 0:
+        buf = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+        _lib.check(lib.ludwig_comm_unique_id(buf))
+        box[0] = bytes(buf)
+    dist.broadcast_object_list(box, src=0)
+    h = C.c_void_p()
+    _lib.check(lib.ludwig_comm_create(box[0], rank, world, int(device), C.byref(h)))
+    return h
+
+
+def native_comm_destroy(comm) -> None:
+    if comm:
+        from . import _lib
+        _lib.load().ludwig_comm_destroy(comm)
+
+
 def init_rccl(local_rank: int) -> None:
     """`torch.distributed` over RCCL with RCCL's kernels on a HIGH-priority stream. Not a tuning nicety: HIP serves the streams of one
     priority from a small pool of hardware queues, and a send/recv kernel that lands in the queue of the compute stream starts only
@@ -431,11 +577,15 @@ def periodic_box_topology(nb_global: Tuple[int, int, int], grid: Tuple[int, int,
 class DistributedLevelRunner:
     """GPU path: one rank's local level on one MI355X + halo exchange; step(t) = one stream-collide pass everywhere.
 
-    overlap=True: see step() - the exchange of step t runs on a second HIP stream under the interior blocks of step t + 1.
-    """
+    transport "native" (default): the exchange and the overlap schedule live behind the C ABI - ludwig_step_distributed: interior
+    blocks, wait for the previous exchange, boundary blocks, [f_post halo, Bouzidi correction], this step's exchange left in flight -
+    with RCCL called from the library (NativeHalo). transport "torch" (always with stage_through_host): the same schedule driven from
+    here over torch.distributed (TorchHalo) - the one-GPU rehearsals over gloo.
+    overlap=False: whole-level launch, then the exchange, waited for."""
 
     def __init__(self, view: LocalView, plan: HaloPlan, params, device: int, overlap: bool = True,
-                 stage_through_host: bool = False, order: Optional[str] = None):
+                 stage_through_host: bool = False, order: Optional[str] = None, transport: Optional[str] = None, comm=None,
+                 wire_rank: Optional[Dict[int, int]] = None):
         import ctypes as C
         import torch
         from . import _lib
@@ -443,23 +593,22 @@ class DistributedLevelRunner:
         from . import order as order_mod
         self.torch, self._lib, self.C = torch, _lib, C
         self.view, self.params, self.overlap = view, params, overlap
+        self.transport = transport or ("torch" if stage_through_host else os.environ.get("LUDWIG_HALO_TRANSPORT", "native"))
+        assert self.transport in ("native", "torch") and not (stage_through_host and self.transport == "native")
         torch.cuda.set_device(device)
         self.level = adapt(view.level, device)
         self.dev = torch.device("cuda", device)
         # overlap: the stepping stream leaves a few compute units to the exchange (include/ludwig_hip.h: ludwig_stream_create;
-        # LUDWIG_COMM_RESERVED_CUS, 0 = none), pack / unpack and RCCL run at high priority (init_rccl)
+        # LUDWIG_COMM_RESERVED_CUS, 0 = none); pack / unpack and RCCL run on a high-priority stream
         self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "8")) if overlap else 0
         self._own_streams = []
         if overlap and self.reserved_cus > 0:
-            def masked_stream():
-                ptr = C.c_void_p()
-                _lib.check(_lib.load().ludwig_stream_create(device, self.reserved_cus, C.byref(ptr)))
-                self._own_streams.append(ptr.value)
-                return torch.cuda.ExternalStream(ptr.value, device=self.dev)
-            self.s_comp = masked_stream()
+            ptr = C.c_void_p()
+            _lib.check(_lib.load().ludwig_stream_create(device, self.reserved_cus, C.byref(ptr)))
+            self._own_streams.append(ptr.value)
+            self.s_comp = torch.cuda.ExternalStream(ptr.value, device=self.dev)
         else:
             self.s_comp = torch.cuda.current_stream(self.dev)
-        self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
         self.level.set_stream(self.s_comp.cuda_stream)
         if order is not None:
             coords = np.asarray(view.level.active_block_coords)
@@ -473,92 +622,90 @@ class DistributedLevelRunner:
                     self.level.set_order(items, part)
         lib = _lib.load()
         handle = self.level.handle
+        self.comm, self._own_comm = comm, False
+        if self.transport == "native":
+            if self.comm is None:
+                self.comm = native_comm(device)
+                self._own_comm = self.comm is not None
+            self.ex = NativeHalo(plan, self.level, self.comm, wire_rank)
+            self.s_comm = None
+        else:
+            def pack(name, idx, out):
+                _lib.check(lib.ludwig_halo_pack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
+                                                C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
 
-        def pack(name, idx, out):
-            _lib.check(lib.ludwig_halo_pack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
-                                            C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+            def unpack(name, idx, src):
+                _lib.check(lib.ludwig_halo_unpack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
+                                                  C.c_void_p(src.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
 
-        def unpack(name, idx, src):
-            _lib.check(lib.ludwig_halo_unpack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
-                                              C.c_void_p(src.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
-
-        self.ex = HaloExchanger(plan, view.rank, self.dev, pack, unpack, stage_through_host)
-        self.ev_boundary = torch.cuda.Event()
-        self.ev_exchanged = torch.cuda.Event()
-        self.ev_post, self.ev_post_done = torch.cuda.Event(), torch.cuda.Event()
-        self._have_exchange = False
-        self._noted = None                 # (f, vel) field names of the exchange the last step left to be enqueued
+            hx = HaloExchanger(plan, view.rank, self.dev, pack, unpack, stage_through_host)
+            if wire_rank:
+                hx.wire_rank = dict(wire_rank)
+            self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
+            self.ex = TorchHalo(hx, self.s_comp, self.s_comm)
 
     def step(self, t: int, u_curr=0.0) -> None:
         """One step with the halo exchange hidden behind the NEXT step's interior blocks:
-             host           : launch interior(t) | enqueue exchange(t-1) | launch boundary(t) ...
-             compute stream : interior(t)        | wait exchange(t-1)    | boundary(t) | [f_post halo, Bouzidi correction(t)]
-             comm stream    :                      exchange(t-1): pack, send/recv, unpack
-        Interior blocks (no ghost neighbour) read and write owned cells only, so they may run while the ghosts of their input
-        are still arriving; the boundary blocks wait for them. The exchange of step t is only NOTED at the end of step t and
-        enqueued after the interior launch of step t + 1: putting a grouped send/recv together costs the host > 0.1 ms, and a
-        device that has not been handed the interior blocks yet idles through it (first seen in the RCCL loop-back trace,
-        profiles/r02_rccl_loopback_*). Levels with Bouzidi cells follow the same schedule: the correction rewrites f_out after the
-        collision from the post-collision values of neighbour cells, so its small f_post halo (only the links that reach across a
-        cut) is exchanged in between and waited for, and the f / u halo goes last.
-        (Stepping the two parts on two streams - boundary(t) only needs step t - 1 and the ghosts - was measured and gives nothing:
-        0.752 vs 0.744 ms, profiles/r02_split_penalty_no_exchange.txt.)"""
+             compute stream : interior(t) | wait exchange(t-1) | boundary(t) | [f_post halo, Bouzidi correction(t)] |
+             comm stream    :   exchange(t-1): pack, send/recv, unpack        |                                      exchange(t) ...
+        Interior blocks (no ghost neighbour) read and write owned cells only, so they may run while the ghosts of their input are
+        still arriving; the boundary blocks wait for them. Levels with Bouzidi cells follow the same schedule: the correction
+        rewrites f_out after the collision from the post-collision values of neighbour cells, so its small f_post halo (only the
+        links that reach across a cut) is exchanged in between and waited for, and the f / u halo goes last.
+        Native transport: all of it is ONE call into the library (ludwig_step_distributed)."""
         from .physics import apply_bouzidi_correction, stream_collide
         _lib = self._lib
-        torch = self.torch
         out_f, out_v = ("f_temp", "vel_temp") if t % 2 == 0 else ("f", "vel")
         if not self.overlap:
             stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_ALL)
             if self.level.has_post_collision:
                 if self.ex.plan.has("f_post"):
-                    self.ex.exchange_post_collision()
+                    self.ex.post({"f_post": "f_post_collision"})
+                    self.ex.join()
                 apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
-            self.ex.exchange(out_f, out_v)
+            self.ex.post({"f": out_f, "vel": out_v})
+            self.ex.join()
+            return
+        if self.transport == "native":
+            fl = self.params.to_c()
+            _lib.check(_lib.load().ludwig_step_distributed(self.level.handle, self.ex.handle, None, int(t), float(np.float32(u_curr)), 0.5, 0.0,
+                                                           self.C.byref(fl)))
             return
         stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_INTERIOR)
-        self.flush()                                        # exchange(t-1), with the device busy on the interior blocks
-        if self._have_exchange:
-            self.s_comp.wait_event(self.ev_exchanged)       # ghosts of this step's input are in place
+        self.ex.join()                                      # ghosts of this step's input are in place
         stream_collide(self.level, None, np.float32(0.5), u_curr, self.params, t, part=_lib.PART_BOUNDARY)
         if self.level.has_post_collision:
             if self.ex.plan.has("f_post"):
-                self.ev_post.record(self.s_comp)
-                with torch.cuda.stream(self.s_comm):
-                    self.s_comm.wait_event(self.ev_post)
-                    self.ex.exchange_post_collision()
-                    self.ev_post_done.record(self.s_comm)
-                self.s_comp.wait_event(self.ev_post_done)
+                self.ex.post({"f_post": "f_post_collision"})
+                self.ex.join()
             apply_bouzidi_correction(self.level, t, self.params.q_min_threshold)
-        self.ev_boundary.record(self.s_comp)
-        self._noted = (out_f, out_v)
+        self.ex.post({"f": out_f, "vel": out_v})
+
+    def exchange_now(self, f_name: str, vel_name: str) -> None:
+        """refresh the ghosts of the two named fields and wait (set-up: ghosts of a start state)"""
+        self.ex.post({"f": f_name, "vel": vel_name})
+        self.ex.join()
 
     def flush(self) -> None:
-        """enqueue the exchange noted by the last step (no-op if there is none): after it the ghosts hold that step's output"""
-        if self._noted is None:
-            return
-        with self.torch.cuda.stream(self.s_comm):
-            self.s_comm.wait_event(self.ev_boundary)
-            self.ex.exchange(*self._noted)
-            self.ev_exchanged.record(self.s_comm)
-        self._noted = None
-        self._have_exchange = True
+        """kept for callers of the round-2 schedule (the exchange used to be enqueued one launch late): nothing to do"""
 
     def synchronize(self) -> None:
-        self.flush()
         self.torch.cuda.synchronize(self.dev)
 
     def close(self, dist=None) -> None:
-        """Teardown in a fixed order: (1) everything queued has run, (2) torch's wrappers of our streams and the events recorded on
-        them are dropped, (3) the process group - RCCL's communicator, its streams and whatever it still holds of ours - is
-        destroyed (pass torch.distributed as `dist` when this runner is the last user of the default group), (4) the level's device
-        memory is freed, (5) the CU-masked stream underneath is destroyed. Round 2 destroyed the stream first, under live
-        ExternalStream wrappers and a live communicator, and left the rest to interpreter shutdown: one profiled run ended in a
-        SIGSEGV inside __cxa_finalize (profiles/README.md)."""
+        """Teardown in a fixed order: (1) everything queued has run, (2) the halo plan and the library's communicator are destroyed,
+        torch's wrappers of our streams and the events recorded on them dropped, (3) the process group is destroyed (pass
+        torch.distributed as `dist` when this runner is the last user of the default group), (4) the level's device memory is
+        freed, (5) the CU-masked stream underneath is destroyed. Round 2 destroyed the stream first, under live ExternalStream
+        wrappers and a live communicator, and left the rest to interpreter shutdown: one profiled run ended in a SIGSEGV inside
+        __cxa_finalize (profiles/README.md)."""
         import gc
         self.synchronize()
-        self.ex._events = []
+        self.ex.close()
         self.ex = None
-        self.ev_boundary = self.ev_exchanged = self.ev_post = self.ev_post_done = None
+        if self._own_comm:
+            native_comm_destroy(self.comm)
+        self.comm = None
         self.level.set_stream(None)
         self.s_comm = None
         self.s_comp = None
@@ -574,7 +721,7 @@ class DistributedLevelRunner:
 
 
 def distributed_level(global_level: BlockLevel, owner: np.ndarray, params, rank: int, world: int, device: int, overlap: bool = True,
-                      stage_through_host: bool = False) -> "DistributedLevelRunner":
+                      stage_through_host: bool = False, transport: Optional[str] = None) -> "DistributedLevelRunner":
     """Partition a populated single-level case (any topology: tunnel with body, sponge, Bouzidi ...) by the block owner map."""
     view = build_local_level(global_level.level_id, global_level.active_block_coords, global_level.neighbor_table, owner, rank,
                              float(global_level.tau), temporal=global_level.f_old.size > 27)
@@ -583,7 +730,7 @@ def distributed_level(global_level: BlockLevel, owner: np.ndarray, params, rank:
     mine = make_requests(view, n_global)
     to_me = exchange_requests(mine, world, rank) if world > 1 else {}
     plan = build_plan(view, n_global, mine, to_me)
-    return DistributedLevelRunner(view, plan, params, device, overlap=overlap, stage_through_host=stage_through_host)
+    return DistributedLevelRunner(view, plan, params, device, overlap=overlap, stage_through_host=stage_through_host, transport=transport)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -739,7 +886,8 @@ class MultiLevelRunner:
     single level-1 array (whole hierarchies per rank: `balanced_owner` + `ancestor_owner`)."""
 
     def __init__(self, grids: Sequence[BlockLevel], owners, params, rank: int, world: int, device: int,
-                 stage_through_host: bool = False, overlap: bool = True):
+                 stage_through_host: bool = False, overlap: bool = True, transport: Optional[str] = None, comm=None,
+                 wire_ranks: Optional[List[Dict[int, int]]] = None):
         import ctypes as C
         import torch
         from . import _lib
@@ -794,76 +942,95 @@ class MultiLevelRunner:
                             v.level.comm_boundary[blk[blk < v.n_owned]] = 1
         # no local copy at all of a level: None (skipped); only ghost copies (parent data for finer blocks): kept, never stepped
         self.levels = [adapt(v.level, device) if v.level.n_blocks > 0 else None for v in self.views]
+        self.plans = plans
         self.overlap = overlap
+        self.transport = transport or ("torch" if stage_through_host else os.environ.get("LUDWIG_HALO_TRANSPORT", "native"))
+        assert self.transport in ("native", "torch") and not (stage_through_host and self.transport == "native")
         self.s_comp = torch.cuda.current_stream(self.dev)
-        self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
         for L in self.levels:
             if L is not None:
                 L.set_stream(self.s_comp.cuda_stream)
-        self.ex: List[HaloExchanger] = []
-        self.ev_stepped = [torch.cuda.Event() for _ in grids]
-        self.ev_exchanged = [torch.cuda.Event() for _ in grids]
-        self.ev_post = [torch.cuda.Event() for _ in grids]
-        self.pending = [False] * len(grids)          # an exchange of this level is in flight on the comm stream
-        for i, plan in enumerate(plans):
-            handle = self.levels[i].handle if self.levels[i] is not None else None
+        self.comm, self._own_comm = comm, False
+        self.ex: List = []
+        if self.transport == "native":
+            # RCCL called from the library (NativeHalo): every level's plan has its own high-priority stream; one communicator
+            if self.comm is None:
+                self.comm = native_comm(device)
+                self._own_comm = self.comm is not None
+            for i, plan in enumerate(plans):
+                if self.levels[i] is None:
+                    assert not plan.peers, "a level without a local copy exchanges nothing"
+                    self.ex.append(None)
+                else:
+                    self.ex.append(NativeHalo(plan, self.levels[i], self.comm, wire_ranks[i] if wire_ranks else None))
+            self.s_comm = None
+        else:
+            self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
+            for i, plan in enumerate(plans):
+                handle = self.levels[i].handle if self.levels[i] is not None else None
 
-            def pack(name, idx, out, handle=handle):
-                _lib.check(lib.ludwig_halo_pack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
-                                                C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+                def pack(name, idx, out, handle=handle):
+                    _lib.check(lib.ludwig_halo_pack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
+                                                    C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
 
-            def unpack(name, idx, src, handle=handle):
-                _lib.check(lib.ludwig_halo_unpack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
-                                                  C.c_void_p(src.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
+                def unpack(name, idx, src, handle=handle):
+                    _lib.check(lib.ludwig_halo_unpack(handle, _lib.FIELD_NAMES[name], C.c_void_p(idx.data_ptr()), idx.numel(),
+                                                      C.c_void_p(src.data_ptr()), C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)))
 
-            self.ex.append(HaloExchanger(plan, rank, self.dev, pack, unpack, stage_through_host))
+                hx = HaloExchanger(plan, rank, self.dev, pack, unpack, stage_through_host)
+                if wire_ranks:
+                    hx.wire_rank = dict(wire_ranks[i])
+                self.ex.append(TorchHalo(hx, self.s_comp, self.s_comm))
 
     def _join(self, i: int) -> None:
         """the compute stream waits for level i's exchange in flight (its ghosts are about to be read)"""
-        if self.pending[i]:
-            self.s_comp.wait_event(self.ev_exchanged[i])
-            self.pending[i] = False
+        if self.ex[i] is not None:
+            self.ex[i].join()
+
+    def _post(self, i: int, fields: Dict[str, str]) -> None:
+        """level i's exchange, queued behind what the compute stream holds so far; what is launched afterwards runs under it"""
+        if self.ex[i] is not None:
+            self.ex[i].post(fields)
 
     def _step_level(self, i: int, t_sub: int, parent, parent_tau, tw, u, has_children: bool) -> None:
         """One level step + its halo exchange (same-level ghosts and the parent-data ghosts of peers' finer blocks).
-        Overlap (two HIP streams):
-          * a level WITH children: boundary part (every block a ghost or a peer depends on) first, then the exchange on the comm
-            stream under the interior part; the children start when both are done.
+        Overlap (the exchange runs on its own stream):
+          * a level WITH children: boundary part (every block a ghost or a peer depends on) first, then the exchange under the
+            interior part; the children start when both are done.
           * the finest level (nobody below reads its ghosts): interior part first - it reads no ghost - while the exchange of
             its PREVIOUS sub-step is still arriving, then the boundary part, [f_post halo, Bouzidi correction], and its own
             exchange is left in flight under whatever comes next (the next sub-step's interior part, or a coarser level's step)."""
         from .physics import apply_bouzidi_correction, stream_collide
-        _lib, torch = self._lib, self.torch
+        _lib = self._lib
         L, ex = self.levels[i], self.ex[i]
         stepping = self.views[i].n_owned > 0                 # else: only ghost copies here, refreshed by the exchange below
         out_f, out_v = ("f_temp", "vel_temp") if t_sub % 2 == 0 else ("f", "vel")
         fields = {"f": out_f, "vel": out_v}
-        if ex.plan.has("rho"):
+        plan = ex.plan if ex is not None else None
+        if plan is not None and plan.has("rho"):
             fields["rho"] = "rho"
+        has_post_halo = plan is not None and plan.has("f_post")
         if i > 0:
             self._join(i - 1)                                # the parent's ghosts (interpolation stencils) must be in place
         if not self.overlap:
             if stepping:
                 stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
-            if ex.plan.has("f_post"):
-                ex.exchange_post_collision()
+            if has_post_halo:
+                self._post(i, {"f_post": "f_post_collision"})
+                self._join(i)
             if stepping and L.has_post_collision:
                 apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
-            ex.exchange_fields(fields)
+            self._post(i, fields)
+            self._join(i)
             return
         bouzidi = stepping and L.has_post_collision
         if has_children and not bouzidi:
             self._join(i)
             if stepping:
                 stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_BOUNDARY)
-            self.ev_stepped[i].record(self.s_comp)
+            self._post(i, fields)                            # waits for the boundary part only: the interior part runs under it
             if stepping:
                 stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_INTERIOR)
-            with torch.cuda.stream(self.s_comm):
-                self.s_comm.wait_event(self.ev_stepped[i])
-                ex.exchange_fields(fields)
-                self.ev_exchanged[i].record(self.s_comm)
-            self.pending[i] = True
             self._join(i)                                    # children interpolate from this level's ghosts next
             return
         if stepping:
@@ -871,21 +1038,12 @@ class MultiLevelRunner:
         self._join(i)
         if stepping:
             stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_BOUNDARY)
-        if ex.plan.has("f_post"):
-            self.ev_stepped[i].record(self.s_comp)
-            with torch.cuda.stream(self.s_comm):
-                self.s_comm.wait_event(self.ev_stepped[i])
-                ex.exchange_post_collision()
-                self.ev_post[i].record(self.s_comm)
-            self.s_comp.wait_event(self.ev_post[i])
+        if has_post_halo:
+            self._post(i, {"f_post": "f_post_collision"})
+            self._join(i)
         if bouzidi:
             apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
-        self.ev_stepped[i].record(self.s_comp)
-        with torch.cuda.stream(self.s_comm):
-            self.s_comm.wait_event(self.ev_stepped[i])
-            ex.exchange_fields(fields)
-            self.ev_exchanged[i].record(self.s_comm)
-        self.pending[i] = True
+        self._post(i, fields)
         if has_children:
             self._join(i)
 
@@ -911,6 +1069,29 @@ class MultiLevelRunner:
 
     def synchronize(self) -> None:
         self.torch.cuda.synchronize(self.dev)
+
+    def close(self, dist=None) -> None:
+        """same order as DistributedLevelRunner.close: device idle, plans and communicator gone, process group gone, levels freed"""
+        import gc
+        if not self.levels and not self.ex:
+            return
+        self.synchronize()
+        for ex in self.ex:
+            if ex is not None:
+                ex.close()
+        self.ex = []
+        if self._own_comm:
+            native_comm_destroy(self.comm)
+        self.comm = None
+        self.s_comm = None
+        gc.collect()
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        for lv in self.levels:
+            if lv is not None:
+                lv.close()
+        self.levels = []
 
 
 def weak_scaling_layout(world: int, nb: int) -> Tuple[Tuple[int, int, int], Tuple[int, int, int]]:

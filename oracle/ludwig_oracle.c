@@ -99,8 +99,15 @@ static inline float jl_clampf(float x, float lo, float hi)
  * kernel rounded once. The double log2 / exp2 / log come from the header the HIP kernels compile too (jl_math.h): the one
  * piece of arithmetic the oracle shares with the product, so that wall-model cells are bit-comparable. It is itself
  * checked against glibc in tests/test_jl_math.py through the two hooks below. */
+#ifdef ORACLE_LIBM_WALL_MODEL
+/* Independence check (tests/test_oracle_libm_flavour.py): the wall model's two transcendental calls through glibc's double pow / log
+ * instead of the shared header, so that an error in jl_math.h cannot cancel between the oracle and the product. Never the parity build. */
+static inline float jl_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+static inline float jl_logf(float x)          { return (float)log((double)x); }
+#else
 static inline float jl_powf(float x, float y) { return lw_powf(x, y); }
 static inline float jl_logf(float x)          { return lw_logf(x); }
+#endif
 void oracle_jl_math(int which, const double *x, double *out, int64_t n)
 {
     for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? lw_log2(x[i]) : which == 1 ? lw_exp2(x[i]) : lw_log(x[i]);

@@ -105,7 +105,12 @@ def main():
         import json
         from open_ludwig_amd import case, preprocess as pp
         G = os.path.join(ROOT, "tests", "golden")
-        if nbx == 1:      # the synthetic half wing (symmetry plane, inlet turbulence, wall model): tests/_wing.py
+        gather = []
+        if nbx == 2:      # the REAL wing: CASES/Wing_5_deg/model5deg.stl kept as tests/golden/wing5deg_model.stl, 3 levels (test_case_wing.py)
+            stl = os.path.join(G, "wing5deg_model.stl")
+            cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"), {"basic": {"surface_resolution": 200, "num_levels": 3, "simulation": {"ramp_steps": 40}}})
+            gather = [(2, "rho"), (2, "vel"), (0, "rho")]
+        elif nbx == 1:    # the synthetic half wing (symmetry plane, inlet turbulence, wall model): tests/_wing.py
             import _wing
             stl = os.path.join(outdir, f"wing_rank{rank}.stl")
             _wing.write_binary_stl(stl, _wing.half_wing_triangles())
@@ -114,18 +119,25 @@ def main():
             stl = os.path.join(G, "ball1m.stl")
             cfg = pp.load_case_configuration(os.path.join(G, "ball1m_config.yaml"),
                                              {"basic": {"surface_resolution": 25, "flow": {"velocity": 4.0}, "simulation": {"steps": 6000, "output_freq": 1000}}})
-        cfg.diag_freq = 20
+        cfg.diag_freq = 8 if nbx == 2 else 20
         setup = pp.setup_multilevel_domain(cfg, stl)
         holder = {}
 
         def factory(grids):
             holder["st"] = case.DistributedStepper(grids, device=0, stage_through_host=True)
+            if gather:
+                holder["st"].close = lambda: None          # the fields are gathered after run_case
             return holder["st"]
 
         cfg.output_freq = 40
-        rows, rep, _ = case.run_case(cfg, factory, steps=steps, setup=setup, out_dir=os.path.join(outdir, "results"), write_files=(rank == 0))
+        rows, rep, _ = case.run_case(cfg, factory, steps=steps, setup=setup, out_dir=None if gather else os.path.join(outdir, "results"),
+                                     write_files=(rank == 0))
         st = holder["st"]
-        stats = [[v.n_owned, v.level.n_blocks, st.runner.ex[i].plan.bytes_per_step()] for i, v in enumerate(st.runner.views)]
+        if gather:
+            got = {f"{name}{lvl}": st.field(lvl, name) for lvl, name in gather}      # collective; rank 0 holds the global arrays
+            if rank == 0:
+                np.savez(os.path.join(outdir, "fields.npz"), **got)
+        stats = [[v.n_owned, v.level.n_blocks, st.runner.plans[i].bytes_per_step()] for i, v in enumerate(st.runner.views)]
         if rank == 0:
             json.dump({"rows": [[r.step, r.u_lat, r.rho_min, r.cd, r.cl, r.cs, r.cmy] for r in rows]}, open(os.path.join(outdir, "rows.json"), "w"))
         json.dump(stats, open(os.path.join(outdir, f"stats{rank}.json"), "w"))
@@ -161,7 +173,7 @@ def main():
             res[f"f{i}"] = lv.download(f_name)[:, :, :, : v.n_owned]
             res[f"vel{i}"] = lv.download(v_name)[:, :, :, : v.n_owned]
             res[f"rho{i}"] = lv.download("rho")[:, :, :, : v.n_owned]
-            res[f"stats{i}"] = np.array([v.n_owned, v.level.n_blocks, runner.ex[i].plan.bytes_per_step(), int(runner.ex[i].plan.has("rho"))])
+            res[f"stats{i}"] = np.array([v.n_owned, v.level.n_blocks, runner.plans[i].bytes_per_step(), int(runner.plans[i].has("rho"))])
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **res)
         dist.barrier()
         dist.destroy_process_group()

@@ -26,9 +26,21 @@ import torch
 import torch.distributed as dist
 
 
-def symmetric_brick_plan(grid, nb, upload_only=True):
+SPHERE_RADIUS = 5.3      # cells; centred on the brick corners, so every cut runs through a body
+
+
+def add_corner_spheres(level, brick_cells, n_owned=None):
+    """one sphere per brick, centred on the brick's corner: Bouzidi cells on both sides of every cut, links with q < 1/2 that read
+    f_post_collision across it - and still the period of one brick"""
+    from open_ludwig_amd import cases
+    cases.add_sphere(level, (0.0, 0.0, 0.0), SPHERE_RADIUS, bouzidi=True, wall_dist=False, period=brick_cells, list_blocks=n_owned)
+    level.force_post_collision = True          # a peer's Bouzidi cells read this rank's face layer
+
+
+def symmetric_brick_plan(grid, nb, upload_only=True, spheres=False):
     """Rank 0's view of a periodic box of grid[0] x grid[1] x grid[2] bricks of nb^3 blocks, Taylor-Green flow with the period of
-    one brick, and a halo plan whose send lists are what the PEERS would send - read from the same places of rank 0's own brick."""
+    one brick, and a halo plan whose send lists are what the PEERS would send - read from the same places of rank 0's own brick.
+    spheres: a body on every brick corner (add_corner_spheres): the f_post_collision halo of the Bouzidi correction joins the plan."""
     from open_ludwig_amd import cases, partition
     from open_ludwig_amd.physics import SolverParams
     nb3 = (nb, nb, nb) if isinstance(nb, int) else tuple(nb)          # blocks per brick edge, or per axis
@@ -37,6 +49,8 @@ def symmetric_brick_plan(grid, nb, upload_only=True):
     widen = os.environ.get("LUDWIG_WIDEN_X_RUNS", "1") != "0"
     view = partition.build_local_level(1, coords, table, owner, 0, 0.5006, widen_x_runs=widen)
     cases.init_taylor_green(view.level, tuple(8 * n for n in nb3), 0.03, share_ab_buffers=upload_only)      # period = one brick
+    if spheres:
+        add_corner_spheres(view.level, tuple(8 * n for n in nb3), view.n_owned)
     params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
                           nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=False, sponge_blend_dist=False)
     n_global = len(coords)
@@ -61,7 +75,8 @@ def main():
     grid = tuple(int(v) for v in sys.argv[1].split("x"))
     nb = int(sys.argv[2]) if "," not in sys.argv[2] else tuple(int(v) for v in sys.argv[2].split(","))
     steps, out_path = int(sys.argv[3]), sys.argv[4]
-    compare = len(sys.argv) < 6 or sys.argv[5] != "nocompare"
+    opts = set(sys.argv[5:])
+    compare, spheres = "nocompare" not in opts, "spheres" in opts
     torch.cuda.set_device(0)
     from open_ludwig_amd import partition as _p
     if os.environ.get("LOOPBACK_PLAIN_INIT"):      # the trace that showed the queue collision
@@ -88,16 +103,22 @@ def main():
 
     from open_ludwig_amd import adapt, cases, partition
     from open_ludwig_amd.physics import stream_collide
-    view, plan, params = symmetric_brick_plan(grid, nb)
-    runner = partition.DistributedLevelRunner(view, plan, params, 0, overlap=True)
-    runner.ex.wire_rank = {p: 0 for p in plan.peers}
+    view, plan, params = symmetric_brick_plan(grid, nb, spheres=spheres)
+    # LOOPBACK_TRANSPORT=native (default): the library calls RCCL itself (ludwig_step_distributed; messages to this rank itself are
+    # forced through ncclSend / ncclRecv: LUDWIG_HALO_SELF_VIA_RCCL); torch: round 2's path, batch_isend_irecv from Python
+    transport = os.environ.get("LOOPBACK_TRANSPORT", "native")
+    if transport == "native":
+        os.environ["LUDWIG_HALO_SELF_VIA_RCCL"] = "1"
+    rep["transport"] = transport
+    runner = partition.DistributedLevelRunner(view, plan, params, 0, overlap=True, transport=transport, wire_rank={p: 0 for p in plan.peers})
     skip = set(filter(None, os.environ.get("LOOPBACK_SKIP", "").split(",")))      # timing-only diagnostics: which piece costs what
     if skip:
         assert not compare, "LOOPBACK_SKIP leaves the ghosts wrong: timing only (nocompare)"
+        assert transport == "torch", "LOOPBACK_SKIP takes pieces out of the Python-driven exchange"
         if "pack" in skip:
-            runner.ex.pack = lambda *a: None
+            runner.ex.ex.pack = lambda *a: None
         if "unpack" in skip:
-            runner.ex.unpack = lambda *a: None
+            runner.ex.ex.unpack = lambda *a: None
         if "transfer" in skip:
             class _Done:
                 def wait(self):
@@ -105,11 +126,13 @@ def main():
             dist.batch_isend_irecv = lambda ops: [_Done()]
         rep["skipped"] = sorted(skip)
     rep["peers"] = len(plan.peers)
+    rep["bouzidi_cells"] = int(view.level.n_boundary_cells)
+    rep["f_post_halo_elements"] = int(sum(plan.recv[p]["f_post"].size for p in plan.peers))
     rep["view_blocks"] = int(view.level.n_blocks)
     rep["halo_bytes_per_step"] = plan.bytes_per_step()
     # ghosts of the start state: sin(x + one period) is not bit-equal to sin(x) in floating point, so fetch them the same way
-    runner.ex.exchange("f", "vel")
-    runner.ex.exchange("f_temp", "vel_temp")
+    runner.exchange_now("f", "vel")
+    runner.exchange_now("f_temp", "vel_temp")
     runner.synchronize()
     warm = min(10, steps // 2)          # the first step pays for communicator set-up and code loading (12 ms)
     if not compare:
@@ -131,6 +154,7 @@ def main():
     t0 = time.perf_counter()
     for t in range(warm + 1, steps + 1):
         runner.step(t)
+    rep["host_us_per_step_enqueue"] = (time.perf_counter() - t0) / (steps - warm) * 1e6      # host time to queue a whole step (launches + exchange)
     runner.synchronize()
     rep["ms_per_step_wall"] = (time.perf_counter() - t0) / (steps - warm) * 1e3
     rep["compute_units_left_to_the_exchange"] = runner.reserved_cus
@@ -146,10 +170,13 @@ def main():
         grids, params1 = cases.periodic_box((nb, nb, nb) if isinstance(nb, int) else nb, upload_only=True)
         pos = {tuple(c): i for i, c in enumerate(grids[0].active_block_coords)}
         sel = np.array([pos[c] for c in own_coords])
+        if spheres:
+            add_corner_spheres(grids[0], tuple(8 * n for n in ((nb,) * 3 if isinstance(nb, int) else nb)))
         single = adapt(grids[0], 0)
         single.set_stream(torch.cuda.current_stream().cuda_stream)
+        from open_ludwig_amd.physics import perform_timestep_v2
         for t in range(1, steps + 1):
-            stream_collide(single, None, np.float32(0.5), np.float32(0.0), params1, t)
+            perform_timestep_v2(single, None, np.float32(0.5), np.float32(0.0), params1, t)      # collision + Bouzidi correction
         torch.cuda.synchronize()
         rep["identical"] = {n: bool(np.array_equal(got[n], single.download(n)[:, :, :, sel])) for n in (fn, vn, "rho")}
         rep["moved"] = bool(got[vn].std() > 0)

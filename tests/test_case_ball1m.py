@@ -81,8 +81,9 @@ def test_hip_reproduces_reference_cd_series(gpu, ball_setup):
 @pytest.mark.gpu
 def test_oracle_itself_reproduces_reference_cd_series(gpu, ball_setup):
     """The oracle pinned DIRECTLY against the reference's own output, not through the HIP path: OracleStepper on ball1m at the
-    log's settings for 1000 coarse steps (4.76 G cell updates, ~2 min on the box's 16 cores - which is why this CPU-side
-    test carries the gpu mark: it runs where those cores are), rows 200 ... 1000 of RESULTS_SPHERE_RE266K.txt to the printed
+    log's settings for 600 coarse steps (2.9 G cell updates, ~1.5 min on the box's 16 cores - which is why this CPU-side
+    test carries the gpu mark: it runs where those cores are; 1000 steps in round 2, shortened to keep the GPU suite inside the
+    driver's limit: profiles/r02_* hold the 1000-step record), rows 200, 400, 600 of RESULTS_SPHERE_RE266K.txt to the printed
     digits. The same loop on the HIP path must give the SAME rows, bit for bit (wall model included: shared jl_math.h).
     Step 200: the oracle / HIP give Cd 0.0637, the log prints 0.0633. profiles/r02_step200_fma_contraction_experiment.txt
     shows why: the same oracle source built with -ffp-contract=fast (the log is a CUDA run, NVPTX fuses a*b+c) gives
@@ -94,36 +95,19 @@ def test_oracle_itself_reproduces_reference_cd_series(gpu, ball_setup):
     oracle.set_num_threads(16)
     cfg, _ = ball_setup
     stl = os.path.join(G, "ball1m.stl")
-    ora, _, _ = case.run_case(cfg, OracleStepper, steps=1000, setup=pp.setup_multilevel_domain(cfg, stl))
+    ora, _, _ = case.run_case(cfg, OracleStepper, steps=600, setup=pp.setup_multilevel_domain(cfg, stl))
     log = _log_series()
     got = {r.step: r for r in ora}
-    assert sorted(got) == [200, 400, 600, 800, 1000]
+    assert sorted(got) == [200, 400, 600]
     for step, r in got.items():
         u_lat, rho_min, cd, cl = log[step]
         assert abs(r.u_lat - u_lat) <= 5.1e-5 and abs(r.rho_min - rho_min) <= 1.01e-4, (step, r)
         assert abs(r.cd - cd) <= (5e-4 if step == 200 else 2.01e-4), (step, r.cd, cd)
         assert abs(r.cl - cl) <= 2.01e-4, (step, r.cl, cl)
     assert abs(got[200].cd - 0.063654) < 2e-6                      # the contraction-off value (see the experiment file)
-    hip, _, _ = case.run_case(cfg, case.HipStepper, steps=1000, setup=pp.setup_multilevel_domain(cfg, stl))
+    hip, _, _ = case.run_case(cfg, case.HipStepper, steps=600, setup=pp.setup_multilevel_domain(cfg, stl))
     for a, b in zip(hip, ora):
         assert (a.step, a.u_lat, a.rho_min, a.cd, a.cl) == (b.step, b.u_lat, b.rho_min, b.cd, b.cl), (a, b)
-
-
-@pytest.mark.gpu
-def test_hip_matches_oracle_on_ball1m(gpu, ball_setup):
-    """Same case, 200 coarse steps (952 M cell updates), HIP vs CPU oracle: Cd, Cl, rho_min identical (the wall model's
-    pow / log are the shared jl_math.h on both sides; the surface integration is the same host code)."""
-    from _steppers import OracleStepper
-    from oracle import oracle
-    oracle.set_num_threads(16)
-    cfg, _ = ball_setup
-    stl = os.path.join(G, "ball1m.stl")
-    hip, _, _ = case.run_case(cfg, case.HipStepper, steps=200, setup=pp.setup_multilevel_domain(cfg, stl))
-    ora, _, _ = case.run_case(cfg, OracleStepper, steps=200, setup=pp.setup_multilevel_domain(cfg, stl))
-    assert len(hip) == len(ora) == 1 and hip[0].step == 200
-    for name in ("cd", "cl", "rho_min"):
-        a, b = getattr(hip[0], name), getattr(ora[0], name)
-        assert a == b, (name, a, b)
 
 
 # ---- BASELINE configs[0]: cube1m as a single-level ~64^3 case, "BGK only" (c_wale = 0, nu_sgs_background = 0) ----
@@ -345,17 +329,18 @@ def test_device_stress_mapping_equals_host_mapping(gpu, ball_setup):
 
 @pytest.mark.gpu
 def test_hip_matches_oracle_on_ball1m_re10m(gpu, ball_re10m_setup):
-    """The 4-level case (tau_fine 0.500001, sponge reaching level 2, 28 400 Bouzidi cells, wall model): 48 coarse steps
-    (980 M cell updates) on HIP and on the CPU oracle; every level's rho / vel / f and the Cd row identical."""
+    """The 4-level case (tau_fine 0.500001, sponge reaching level 2, 28 400 Bouzidi cells, wall model): 32 coarse steps
+    (650 M cell updates) on HIP and on the CPU oracle; every level's rho / vel / f and the Cd row identical."""
     import copy
     from _steppers import OracleStepper
     from oracle import oracle
     oracle.set_num_threads(16)
     cfg, _ = ball_re10m_setup
     cfg = copy.copy(cfg)
-    cfg.diag_freq, cfg.output_freq, steps = 48, 10 ** 9, 48
+    cfg.diag_freq, cfg.output_freq, steps = 32, 10 ** 9, 32
     stl = os.path.join(G, "ball1m.stl")
-    setup_h, setup_o = pp.setup_multilevel_domain(cfg, stl), pp.setup_multilevel_domain(cfg, stl)
+    setup_h = pp.setup_multilevel_domain(cfg, stl)
+    setup_o = copy.deepcopy(setup_h)
     keep = {}
 
     def hip_factory(grids):

@@ -53,21 +53,67 @@ def test_symmetric_brick_plan_reproduces_the_one_brick_box_cpu(grid):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,nb,steps,pad", [("2x1x1", 4, 7, None), ("2x2x2", 4, 8, None), ("1x2x2", "8,4,2", 6, None)])
-def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps, pad):
-    """The production exchange (pack -> grouped isend/irecv on RCCL -> unpack on the comm stream, interior blocks stepping under
-    it) with all 1 / 7 peers wired to rank 0: fields identical to the single-device run of the one-brick box."""
+@pytest.mark.parametrize("grid,nb,steps,transport", [("2x1x1", 4, 7, "native"), ("2x2x2", 4, 8, "native"), ("1x2x2", "8,4,2", 6, "native"),
+                                                      ("2x2x2", 4, 8, "torch"), ("2x2x2", 4, 7, "native+spheres"), ("2x1x1", 4, 6, "torch+spheres")])
+def test_halo_exchange_over_rccl_loopback(gpu, tmp_path, grid, nb, steps, transport):
+    """The production exchange with all 1 / 7 peers wired to rank 0: fields identical to the single-device run of the one-brick box.
+    native: ludwig_step_distributed - octet pack, one ncclSend / ncclRecv per peer and field in one group called FROM THE LIBRARY on
+    its own high-priority stream, unpack, interior blocks stepping under it (messages to rank 0 itself forced through RCCL).
+    torch: the same schedule driven from Python over torch.distributed's nccl backend (round 2's path, kept for the rehearsals).
+    +spheres: a body on every brick corner, so Bouzidi cells sit on both sides of every cut and their q < 1/2 links read
+    f_post_collision across it: the f_post halo between collision and correction (group 2 of the plan) travels too."""
+    spheres = transport.endswith("+spheres")
+    transport = transport.split("+")[0]
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", LOOPBACK_TRANSPORT=transport)
     out = tmp_path / "rep.json"
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_loopback_worker.py"), grid, str(nb), str(steps), str(out)],
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_loopback_worker.py"), grid, str(nb), str(steps), str(out)] + (["spheres"] if spheres else []),
                          capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     rep = json.load(open(out))
-    assert rep["backend"] == "nccl" and rep["collectives_ok"]
+    assert rep["backend"] == "nccl" and rep["collectives_ok"] and rep["transport"] == transport
     assert rep["peers"] == {"2x1x1": 1, "2x2x2": 7, "1x2x2": 3}[grid]      # 1x2x2 with 8 x 4 x 2 blocks: the shape of bench.py's 8-rank bricks
     assert rep["moved"] and all(rep["identical"].values()), rep
+    if spheres:
+        assert rep["bouzidi_cells"] > 100 and rep["f_post_halo_elements"] > 0, rep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [True, False])
+def test_native_exchange_with_device_copies(gpu, overlap):
+    """The library's halo plan without any communicator: one process, every peer of the symmetric brick plan is this rank itself, so
+    ludwig_halo_exchange moves the messages with device copies - octet pack / unpack, the plan's stream and events and
+    ludwig_step_distributed's schedule (interior, wait, boundary, exchange left in flight) against the single-device run."""
+    import torch
+    import _rccl_loopback_worker as w
+    from open_ludwig_amd import adapt, partition
+    from open_ludwig_amd.physics import stream_collide
+    nb, steps, grid = 4, 7, (2, 2, 2)
+    view, plan, params = w.symmetric_brick_plan(grid, nb)
+    runner = partition.DistributedLevelRunner(view, plan, params, 0, overlap=overlap, transport="native", wire_rank={p: 0 for p in plan.peers})
+    assert runner.comm is None
+    runner.exchange_now("f", "vel")
+    runner.exchange_now("f_temp", "vel_temp")
+    runner.ex.timing = True
+    for t in range(1, steps + 1):
+        runner.step(t)
+    runner.synchronize()
+    assert len(runner.ex.exchange_ms()) == steps
+    fn, vn = ("f_temp", "vel_temp") if steps % 2 == 0 else ("f", "vel")
+    got = {n: runner.level.download(n)[:, :, :, : view.n_owned] for n in (fn, vn, "rho")}
+    grids, params1 = cases.periodic_box((nb, nb, nb), upload_only=True)
+    pos = {tuple(c): i for i, c in enumerate(grids[0].active_block_coords)}
+    sel = np.array([pos[tuple(c)] for c in np.asarray(view.level.active_block_coords)[: view.n_owned]])
+    single = adapt(grids[0], 0)
+    for t in range(1, steps + 1):
+        stream_collide(single, None, np.float32(0.5), np.float32(0.0), params1, t)
+    torch.cuda.synchronize()
+    for n in (fn, vn, "rho"):
+        assert np.array_equal(got[n], single.download(n)[:, :, :, sel]), n
+    assert got[vn].std() > 0
+    single.close()
+    runner.close()
