@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <string>
 #include <vector>
@@ -77,7 +78,7 @@ struct LudwigLevel {
     // ahead, rho is stored by every step.
     bool external_writer = false;
     int n_bc = 0;
-    int2 *bouzidi_links = nullptr;      // (block * 512 + cell, k) of every listed link with q > 0 (the q map is static)
+    int4 *bouzidi_links = nullptr;      // every listed link with q > 0 (the q map is static): kernels.hpp BouzidiParams::links
     int n_bouzidi_links = 0;
     _Float16 *q_map = nullptr;
     int32_t *cell_block = nullptr;
@@ -114,6 +115,8 @@ struct LudwigLevel {
     float4 *source_w[N_PARTS] = {};     // per source cell: interpolation weights wx, wy, wz
     float4 *source_mac[N_PARTS] = {};   // per source cell, rewritten every pass: interpolated rho, ux, uy, uz
     float4 *source_mac2[N_PARTS] = {};  // the same for the speculated weight of the next sub-step
+    IfaceSource *fused_src[N_PARTS] = {};   // the fused pass (k_interface_fused): one 64-B record per source cell ...
+    uint32_t *fused_outs[N_PARTS] = {};     // ... and one output position per link, grouped by source, ascending k
     float *f_iface2 = nullptr;
     // Interface values computed ahead for the second sub-step of a pair (reference src/solver_control.jl:63-83: the child
     // steps 2t with weight 0.0 and 2t+1 with 0.5 against the same parent buffers): valid while the parent was not written.
@@ -537,13 +540,37 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
             }
             links.push_back(make_int4(l.e.x, l.e.y, (int)weights.size() - 1, 0));
         }
+        // the fused pass: per source its record and the output positions of its links, ascending k
+        std::vector<IfaceSource> fsrc(weights.size());
+        std::vector<uint32_t> fouts(links.size());
+        {
+            if ((int64_t)L->n_iface_blocks * Q * CELLS >= ((int64_t)1 << 32)) return fail(LUDWIG_ERR_INVALID, "too many interface blocks for 32-bit positions");
+            std::vector<std::vector<std::pair<int, uint32_t>>> per((size_t)weights.size());
+            for (const int4 &l : links) {
+                const int k = l.y & 31, gbi = l.y >> 5, cell = l.x & 511;
+                per[(size_t)l.z].push_back({k, (uint32_t)(((size_t)k * L->n_iface_blocks + gbi) * CELLS + cell)});
+            }
+            uint32_t pos = 0;
+            for (size_t si = 0; si < per.size(); ++si) {
+                std::sort(per[si].begin(), per[si].end());
+                IfaceSource &r = fsrc[si];
+                r.c0 = corners[2 * si]; r.c1 = corners[2 * si + 1];
+                r.wx = weights[si].x; r.wy = weights[si].y; r.wz = weights[si].z;
+                r.mask = 0; r.first_out = pos; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                for (const auto &kv : per[si]) {
+                    if (r.mask >> kv.first & 1u) return fail(LUDWIG_ERR_STATE, "interface links: population %d pulled twice from one source cell", kv.first);
+                    r.mask |= 1u << kv.first;
+                    fouts[pos++] = kv.second;
+                }
+            }
+        }
         // launch order of the links: population by population, sources in (z, y, x) order inside. Neighbouring lanes then
         // read neighbouring parent cells of ONE population array (a few 128-B lines per wave-load instead of ~30) and
         // write neighbouring cells of f_iface.
         std::stable_sort(links.begin(), links.end(), [](const int4 &u, const int4 &v) { return (u.y & 31) < (v.y & 31); });
         L->ahead[a2].valid = false;
         void **owned[] = {(void **)&L->links[a2], (void **)&L->sources[a2], (void **)&L->source_w[a2], (void **)&L->source_mac[a2],
-                          (void **)&L->source_mac2[a2]};
+                          (void **)&L->source_mac2[a2], (void **)&L->fused_src[a2], (void **)&L->fused_outs[a2]};
         for (void **q : owned)
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         L->n_links[a2] = (int)links.size();
@@ -557,6 +584,10 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
             LW_HIP(hipMemcpy(L->source_w[a2], weights.data(), weights.size() * sizeof(float4), hipMemcpyHostToDevice));
             LW_HIP(hipMalloc((void **)&L->source_mac[a2], weights.size() * sizeof(float4)));
             LW_HIP(hipMalloc((void **)&L->source_mac2[a2], weights.size() * sizeof(float4)));
+            LW_HIP(hipMalloc((void **)&L->fused_src[a2], fsrc.size() * sizeof(IfaceSource)));
+            LW_HIP(hipMemcpy(L->fused_src[a2], fsrc.data(), fsrc.size() * sizeof(IfaceSource), hipMemcpyHostToDevice));
+            LW_HIP(hipMalloc((void **)&L->fused_outs[a2], fouts.size() * sizeof(uint32_t)));
+            LW_HIP(hipMemcpy(L->fused_outs[a2], fouts.data(), fouts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
     if (!L->f_iface && L->n_iface_blocks > 0) {
@@ -632,6 +663,7 @@ static int interface_launch(LudwigLevel *L, const LudwigLevel *parent, int part,
     // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
     const bool two = (t_sub % 2 == 0) && !parent->external_writer && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
     InterfaceArgs a{};
+    a.src = L->fused_src[part]; a.outs = L->fused_outs[part];
     a.corners = L->sources[part]; a.weights = L->source_w[part];
     a.mac = L->source_mac[part]; a.mac2 = L->source_mac2[part];
     a.links = L->links[part];
@@ -639,7 +671,16 @@ static int interface_launch(LudwigLevel *L, const LudwigLevel *parent, int part,
     a.tw2 = 0.5f;
     a.n_sources = L->n_sources[part]; a.n_links = L->n_links[part];
     const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
-    if (two) {
+    // LUDWIG_IFACE_FUSED=1: both passes in one kernel, one thread per source cell (experiment: slower, profiles/r03_interface_pass_fused_experiment.txt)
+    static const bool two_kernels = getenv("LUDWIG_IFACE_FUSED") == nullptr;
+    if (!two_kernels) {
+        if (two) hipLaunchKernelGGL(k_interface_fused<true>, gs, dim3(256), 0, st, p, a);
+        else hipLaunchKernelGGL(k_interface_fused<false>, gs, dim3(256), 0, st, p, a);
+        if (two) {
+            ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
+            ah.tw = a.tw2; ah.tau_parent = parent_tau; ah.use_temporal = p.use_temporal;
+        }
+    } else if (two) {
         hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, st, p, a);
         hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, st, p, a);
         ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
@@ -970,6 +1011,8 @@ void ludwig_level_destroy(LudwigLevel *L)
         if (L->source_w[a]) (void)hipFree(L->source_w[a]);
         if (L->source_mac[a]) (void)hipFree(L->source_mac[a]);
         if (L->source_mac2[a]) (void)hipFree(L->source_mac2[a]);
+        if (L->fused_src[a]) (void)hipFree(L->fused_src[a]);
+        if (L->fused_outs[a]) (void)hipFree(L->fused_outs[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
     if (L->d_ref2int) (void)hipFree(L->d_ref2int);
@@ -1195,17 +1238,29 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             LW_HIP(hipMemcpy(L->cell_x, cx.data(), cx.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_y, cy.data(), cy.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_z, cz.data(), cz.size(), hipMemcpyHostToDevice));
-            std::vector<int2> bl;
+            std::vector<int4> bl;
             const _Float16 *qh = reinterpret_cast<const _Float16 *>(h->bouzidi_q_map);
             for (int i = 0; i < L->n_bc; ++i) {
                 const int own = cb[i] * CELLS + cx[i] + 8 * cy[i] + 64 * cz[i];
-                for (int k = 0; k < Q; ++k)
-                    if ((float)qh[(size_t)own + c * k] > 0.0f) bl.push_back(make_int2(own, k));
+                for (int k = 0; k < Q; ++k) {
+                    const float q = (float)qh[(size_t)own + c * k];
+                    if (!(q > 0.0f)) continue;
+                    // the cell one step behind along the link (reference src/bouzidi_kernel.jl:47-58): same block, the neighbour block
+                    // of the table, or none (-1: the reference falls back to the cell's own value)
+                    const int ok = 26 - k;
+                    const int nx = cx[i] + CX(ok), ny = cy[i] + CY(ok), nz = cz[i] + CZ(ok);
+                    const int ox = nx < 0 ? -1 : (nx >= BS ? 1 : 0), oy = ny < 0 ? -1 : (ny >= BS ? 1 : 0), oz = nz < 0 ? -1 : (nz >= BS ? 1 : 0);
+                    const int nbb = (ox | oy | oz) == 0 ? cb[i] : L->h_meta[(size_t)cb[i] * NBR_STRIDE + DIR(ox, oy, oz)];
+                    const int behind = nbb >= 0 ? nbb * CELLS + (nx & 7) + 8 * (ny & 7) + 64 * (nz & 7) : -1;
+                    int qbits;
+                    memcpy(&qbits, &q, 4);
+                    bl.push_back(make_int4(own, k, qbits, behind));
+                }
             }
             L->n_bouzidi_links = (int)bl.size();
             if (!bl.empty()) {
-                LW_HIP(hipMalloc((void **)&L->bouzidi_links, bl.size() * sizeof(int2)));
-                LW_HIP(hipMemcpy(L->bouzidi_links, bl.data(), bl.size() * sizeof(int2), hipMemcpyHostToDevice));
+                LW_HIP(hipMalloc((void **)&L->bouzidi_links, bl.size() * sizeof(int4)));
+                LW_HIP(hipMemcpy(L->bouzidi_links, bl.data(), bl.size() * sizeof(int4), hipMemcpyHostToDevice));
             }
         }
         if (L->has_post) {
@@ -1860,9 +1915,10 @@ struct LudwigHaloPlan {
     LudwigComm *comm = nullptr;
     std::vector<int32_t> peers;
     struct Group {
-        int64_t n_send = 0, n_recv = 0, n_send_oct = 0, n_recv_oct = 0;
+        int64_t n_send = 0, n_recv = 0, n_send_oct = 0, n_recv_oct = 0, n_send_single = 0, n_recv_single = 0;
         float *send_buf = nullptr, *recv_buf = nullptr;
         uint4 *send_desc = nullptr, *recv_desc = nullptr;
+        uint2 *send_single = nullptr, *recv_single = nullptr;
         std::vector<int64_t> send_off, recv_off;       // [n_peers + 1] prefix sums
     } g[LUDWIG_HALO_GROUPS];
     hipStream_t s_comm = nullptr;                      // high priority: a queue of its own beside the stepping stream
@@ -1877,9 +1933,10 @@ struct LudwigHaloPlan {
 namespace {
 
 // message elements (reference-layout offsets, in message order) -> octet descriptors of the device array (kernels.hpp: k_pack_octets)
-int build_octets(const LudwigLevel *L, int K, const int64_t *index, int64_t n, std::vector<uint4> &out)
+int build_octets(const LudwigLevel *L, int K, const int64_t *index, int64_t n, std::vector<uint4> &out, std::vector<uint2> &singles)
 {
     out.clear();
+    singles.clear();
     const int64_t sk = L->sk, total = sk * K;
     int64_t cur_oct = -1;
     int last_j = -1;
@@ -1899,6 +1956,17 @@ int build_octets(const LudwigLevel *L, int K, const int64_t *index, int64_t n, s
         out.back().z |= 1u << j;
         last_j = j;
     }
+    // octets with one or two members: one thread per member instead of eight per octet (kernels.hpp)
+    if (n >= ((int64_t)1 << 29)) return fail(LUDWIG_ERR_INVALID, "halo plan: message too long for 29-bit positions");
+    std::vector<uint4> full;
+    full.reserve(out.size());
+    for (const uint4 &d : out) {
+        if (__builtin_popcount(d.z) >= 3) { full.push_back(d); continue; }
+        uint32_t pos = d.y;
+        for (uint32_t j = 0; j < 8; ++j)
+            if ((d.z >> j) & 1u) singles.push_back(make_uint2(d.x, (pos++ << 3) | j));
+    }
+    out.swap(full);
     return LUDWIG_OK;
 }
 
@@ -1906,10 +1974,11 @@ int halo_pack_group(LudwigHaloPlan *P, int group, int field, hipStream_t st)
 {
     LudwigLevel *L = P->L;
     LudwigHaloPlan::Group &G = P->g[group];
-    if (G.n_send_oct == 0) return LUDWIG_OK;
+    if (G.n_send == 0) return LUDWIG_OK;
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || d.es != 4 || d.comps != HALO_GROUP_COMPS[group]) return fail(LUDWIG_ERR_INVALID, "halo group %d cannot move field %d", group, field);
-    hipLaunchKernelGGL(k_pack_octets, dim3((unsigned)((G.n_send_oct * 8 + 255) / 256)), dim3(256), 0, st, (const float *)d.ptr, G.send_desc, G.n_send_oct, G.send_buf);
+    hipLaunchKernelGGL(k_pack_octets, dim3((unsigned)((G.n_send_oct * 8 + G.n_send_single + 255) / 256)), dim3(256), 0, st, (const float *)d.ptr, G.send_desc,
+                       G.n_send_oct, G.send_single, G.n_send_single, G.send_buf);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -1918,10 +1987,11 @@ int halo_unpack_group(LudwigHaloPlan *P, int group, int field, hipStream_t st)
 {
     LudwigLevel *L = P->L;
     LudwigHaloPlan::Group &G = P->g[group];
-    if (G.n_recv_oct == 0) return LUDWIG_OK;
+    if (G.n_recv == 0) return LUDWIG_OK;
     const FieldDesc d = field_desc(L, field);
     if (!d.ptr || d.es != 4 || d.comps != HALO_GROUP_COMPS[group]) return fail(LUDWIG_ERR_INVALID, "halo group %d cannot move field %d", group, field);
-    hipLaunchKernelGGL(k_unpack_octets, dim3((unsigned)((G.n_recv_oct * 8 + 255) / 256)), dim3(256), 0, st, (float *)d.ptr, G.recv_desc, G.n_recv_oct, G.recv_buf);
+    hipLaunchKernelGGL(k_unpack_octets, dim3((unsigned)((G.n_recv_oct * 8 + G.n_recv_single + 255) / 256)), dim3(256), 0, st, (float *)d.ptr, G.recv_desc,
+                       G.n_recv_oct, G.recv_single, G.n_recv_single, G.recv_buf);
     LW_HIP(hipGetLastError());
     return LUDWIG_OK;
 }
@@ -2018,7 +2088,7 @@ void ludwig_halo_plan_destroy(LudwigHaloPlan *P)
     if (P->L) (void)hipSetDevice(P->L->device);
     if (P->s_comm) (void)hipStreamSynchronize(P->s_comm);
     for (auto &G : P->g) {
-        void *ptrs[] = {G.send_buf, G.recv_buf, G.send_desc, G.recv_desc};
+        void *ptrs[] = {G.send_buf, G.recv_buf, G.send_desc, G.recv_desc, G.send_single, G.recv_single};
         for (void *q : ptrs)
             if (q) (void)hipFree(q);
     }
@@ -2048,11 +2118,11 @@ int ludwig_halo_plan_create(LudwigLevel *L, LudwigComm *comm, const LudwigHaloPl
     P->peers.assign(desc->peer_ranks, desc->peer_ranks + desc->n_peers);
     P->self_via_rccl = comm && getenv("LUDWIG_HALO_SELF_VIA_RCCL") != nullptr;
     int rc = LUDWIG_OK;
-    auto upload = [&](const std::vector<uint4> &v, uint4 **dst) -> int {
+    auto upload = [&](const auto &v, auto **dst) -> int {
         *dst = nullptr;
         if (v.empty()) return LUDWIG_OK;
-        LW_HIP(hipMalloc((void **)dst, v.size() * sizeof(uint4)));
-        LW_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        LW_HIP(hipMalloc((void **)dst, v.size() * sizeof(v[0])));
+        LW_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(v[0]), hipMemcpyHostToDevice));
         return LUDWIG_OK;
     };
     for (int g = 0; g < LUDWIG_HALO_GROUPS && rc == LUDWIG_OK; ++g) {
@@ -2070,10 +2140,12 @@ int ludwig_halo_plan_create(LudwigLevel *L, LudwigComm *comm, const LudwigHaloPl
         if ((G.n_send > 0 && !desc->send_index[g]) || (G.n_recv > 0 && !desc->recv_index[g])) { rc = fail(LUDWIG_ERR_INVALID, "group %d: index list missing", g); break; }
         if (g == 2 && (G.n_send || G.n_recv) && !L->has_post) { rc = fail(LUDWIG_ERR_STATE, "group 2 (f_post_collision) on a level without that array"); break; }
         std::vector<uint4> sd, rd;
-        if ((rc = build_octets(L, HALO_GROUP_COMPS[g], desc->send_index[g], G.n_send, sd))) break;
-        if ((rc = build_octets(L, HALO_GROUP_COMPS[g], desc->recv_index[g], G.n_recv, rd))) break;
+        std::vector<uint2> ss, rs;
+        if ((rc = build_octets(L, HALO_GROUP_COMPS[g], desc->send_index[g], G.n_send, sd, ss))) break;
+        if ((rc = build_octets(L, HALO_GROUP_COMPS[g], desc->recv_index[g], G.n_recv, rd, rs))) break;
         G.n_send_oct = (int64_t)sd.size(); G.n_recv_oct = (int64_t)rd.size();
-        if ((rc = upload(sd, &G.send_desc)) || (rc = upload(rd, &G.recv_desc))) break;
+        G.n_send_single = (int64_t)ss.size(); G.n_recv_single = (int64_t)rs.size();
+        if ((rc = upload(sd, &G.send_desc)) || (rc = upload(rd, &G.recv_desc)) || (rc = upload(ss, &G.send_single)) || (rc = upload(rs, &G.recv_single))) break;
         hipError_t e = hipSuccess;
         if (G.n_send) e = hipMalloc((void **)&G.send_buf, (size_t)G.n_send * 4);
         if (e == hipSuccess && G.n_recv) e = hipMalloc((void **)&G.recv_buf, (size_t)G.n_recv * 4);
@@ -2146,9 +2218,20 @@ int ludwig_halo_plan_buffers(const LudwigHaloPlan *P, int32_t group, void **send
     return LUDWIG_OK;
 }
 
+static double host_now_us()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
 int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, const int32_t *fields)
 {
     if (!P || n < 0 || n > LUDWIG_HALO_GROUPS || (n > 0 && (!groups || !fields))) return fail(LUDWIG_ERR_INVALID, "bad argument");
+    // LUDWIG_HALO_TRACE=1: host microseconds of the three parts of this call on stderr (what an exchange costs the host)
+    static const bool trace = getenv("LUDWIG_HALO_TRACE") != nullptr;
+    const double h0 = trace ? host_now_us() : 0.0;
+    double h1 = 0.0, h2 = 0.0;
     LudwigLevel *L = P->L;
     LW_HIP(hipSetDevice(L->device));
     for (int i = 0; i < n; ++i) {
@@ -2165,6 +2248,7 @@ int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, co
         const int r = halo_pack_group(P, groups[i], fields[i], P->s_comm);
         if (r) return r;
     }
+    if (trace) h1 = host_now_us();
     RcclApi *api = P->comm ? rccl() : nullptr;
     bool any_remote = false;
     for (size_t p = 0; p < P->peers.size(); ++p)
@@ -2186,6 +2270,7 @@ int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, co
         }
     }
     if (any_remote) LW_NCCL(api, api->GroupEnd());
+    if (trace) h2 = host_now_us();
     for (int i = 0; i < n; ++i) {
         const int r = halo_unpack_group(P, groups[i], fields[i], P->s_comm);
         if (r) return r;
@@ -2193,6 +2278,7 @@ int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, co
     if (P->timing) { LW_HIP(hipEventRecord(P->t1[slot], P->s_comm)); ++P->n_timed; }
     LW_HIP(hipEventRecord(P->ev_done, P->s_comm));
     P->pending = true;
+    if (trace) fprintf(stderr, "[ludwig_halo_exchange] host us: events + pack %.1f, send/recv group (%zu peers) %.1f, unpack + event %.1f\n", h1 - h0, P->peers.size(), h2 - h1, host_now_us() - h2);
     return LUDWIG_OK;
 }
 

@@ -1,5 +1,5 @@
 """Turn rocprofv3 CSV output (kernel trace + PMC passes) into the small text/JSON summaries committed under profiles/."""
-import csv, glob, json, os, sys, collections
+import csv, glob, json, os, re, sys, collections
 
 def kernel_stats(trace_dir):
     rows = []
@@ -20,8 +20,8 @@ def pmc(dirs, kernel_substr):
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
-                # the RHO_ONLY replay launch (last template argument true) is a different kernel: keep it out of the averages
-                if kernel_substr in r["Kernel_Name"] and ", true>(lw::SCParams)" not in r["Kernel_Name"]:
+                # the RHO_ONLY replay launch (fifth template argument true) is a different kernel: keep it out of the averages
+                if kernel_substr in r["Kernel_Name"] and not re.search(r"true, (true|false)>\(lw::SCParams\)", r["Kernel_Name"]):
                     vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in vals.items()}
 
@@ -39,7 +39,7 @@ if __name__ == "__main__":
     import datetime
     res = {"cells_per_launch": cells, "counters_per_launch": c, "source_digest": build_mod.source_digest(),
            "captured": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d %H:%M UTC"),
-           "kernel": "lw::k_stream_collide_xrun<4,false,false,false> at 256^3, library default order, rho store elided"}
+           "kernel": "void lw::k_stream_collide_xrun<4, false, false, false, false, false>(lw::SCParams) at 256^3, library default order, rho store elided"}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # MI355X_MICROARCH.md "HBM": FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B read requests
         # at 64 B -> double it; WRITE_SIZE is exact. Separate --pmc passes (TCC has 4 slots: FETCH 3 + WRITE 2 do not fit).
