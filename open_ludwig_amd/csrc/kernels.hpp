@@ -744,18 +744,7 @@ __device__ __forceinline__ float weight_rt(int k)
 // The two sub-steps a child level takes per parent step see the SAME parent buffers and differ only in the temporal
 // weight (0.0 then 0.5, reference src/solver_control.jl:63-83). With TWO = true both values are produced from one set of
 // loads (second outputs mac2 / f_iface2 for weight tw2); the second sub-step then skips the pass.
-// fused pass (k_interface_fused): everything static about one source cell in one 64-B record
-struct IfaceSource {
-    int4 c0, c1;              // parent-cell offsets of the 8 stencil corners (block * 512 + cell), -1 = absent
-    float wx, wy, wz;         // interpolation weights
-    uint32_t mask;            // populations k pulled from this cell (one link each), bit k
-    uint32_t first_out;       // index of its first entry in InterfaceArgs::outs (one per set bit, ascending k)
-    uint32_t pad[3];
-};
-
 struct InterfaceArgs {
-    const IfaceSource *src;   // fused pass: per source
-    const uint32_t *outs;     // fused pass: per link, position of its value in f_iface: (k * n_iface_blocks + gbi) * 512 + cell
     const int4 *corners;      // 2 per source: parent-cell offsets of the 8 stencil corners, -1 = absent (static, host)
     const float4 *weights;    // per source: wx, wy, wz (static)
     float4 *mac, *mac2;       // per source: interpolated rho, ux, uy, uz for tw / tw2
@@ -865,94 +854,8 @@ __global__ __launch_bounds__(256) void k_interface_links(const SCParams p, const
     }
 }
 
-// Both passes in ONE kernel, one thread per SOURCE cell (round 3). The two-kernel form reads, per LINK, the source's 48 B of
-// corners / weights, its 32 B of interpolated moments and its own 16-B record - mostly the same bytes nine times over, once
-// per population pulled from that cell - and needs the moments to make a round trip through memory between two launches.
-// Here a thread loads its source's record once, interpolates rho / u in registers, then walks the populations of its mask:
-// 8 (16 with the blend in time) parent loads, the same trilinear / equilibrium / rescale expressions, one (two) stores each.
-// Same values bit for bit; wing: 42 + 22 us per pair of sub-steps -> see DESIGN.md 3.3.
-template <bool TWO>
-__global__ __launch_bounds__(256) void k_interface_fused(const SCParams p, const InterfaceArgs a)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n_sources) return;
-    const IfaceSource s = a.src[i];
-    const int cc[8] = {s.c0.x, s.c0.y, s.c0.z, s.c0.w, s.c1.x, s.c1.y, s.c1.z, s.c1.w};
-    const float tw = p.temporal_weight, tw2 = a.tw2;
-    const bool blend = p.use_temporal == 1 && tw < 0.99f, blend2 = TWO && p.use_temporal == 1 && tw2 < 0.99f;
-    // ---- pass 1 of the two-kernel form: rho, u at the 8 corners, blended in time, trilinear (k_interface_sources) ----
-    float v1[4][8], v2[4][8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        v1[0][n] = 1.0f; v1[1][n] = 0.0f; v1[2][n] = 0.0f; v1[3][n] = 0.0f;      // (w_k, 1, 0, 0, 0, false) default
-        v2[0][n] = 1.0f; v2[1][n] = 0.0f; v2[2][n] = 0.0f; v2[3][n] = 0.0f;
-        if (cc[n] >= 0) {
-            const int c = cc[n];
-            const size_t cv = (size_t)(c >> 9) * (3 * CELLS) + (c & 511);
-            const float vn[4] = {p.prho_new[c], p.pvel_new[cv], p.pvel_new[cv + CELLS], p.pvel_new[cv + 2 * CELLS]};
-            float vo[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (blend || blend2) { vo[0] = p.prho_old[c]; vo[1] = p.pvel_old[cv]; vo[2] = p.pvel_old[cv + CELLS]; vo[3] = p.pvel_old[cv + 2 * CELLS]; }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v1[q][n] = blend_in_time(blend, vo[q], vn[q], tw);
-                if (TWO) v2[q][n] = blend_in_time(blend2, vo[q], vn[q], tw2);
-            }
-        }
-    }
-#pragma unroll
-    for (int n = 1; n < 8; ++n)
-        if (cc[n] < 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { v1[q][n] = v1[q][0]; v2[q][n] = v2[q][0]; }
-        }
-#define LW_TL(v, q) trilin(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5], v[q][6], v[q][7], s.wx, s.wy, s.wz)
-    const float4 m1 = make_float4(LW_TL(v1, 0), LW_TL(v1, 1), LW_TL(v1, 2), LW_TL(v1, 3));
-    float4 m2 = m1;
-    if (TWO) m2 = make_float4(LW_TL(v2, 0), LW_TL(v2, 1), LW_TL(v2, 2), LW_TL(v2, 3));
-#undef LW_TL
-    // ---- pass 2: the populations pulled from this cell (k_interface_links) ----
-    const float tau_c = p.tau_parent - 0.5f, tau_f = p.tau - 0.5f;
-    const float scale = tau_c > 1.0e-6f ? jl_clamp(tau_f / tau_c, 0.01f, 100.0f) : 1.0f;
-    size_t cb[8];                                              // population 0 of every corner's parent cell
-#pragma unroll
-    for (int n = 0; n < 8; ++n) cb[n] = cc[n] >= 0 ? (size_t)(cc[n] >> 9) * (Q * CELLS) + (cc[n] & 511) : 0;
-    uint32_t mask = s.mask;
-    const uint32_t *outs = a.outs + s.first_out;
-    while (mask) {
-        const int k = __ffs(mask) - 1;
-        mask &= mask - 1;
-        const uint32_t out = *outs++;
-        const float w_k = weight_rt(k);
-        float fc[8], fc2[8];
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            fc[n] = w_k; fc2[n] = w_k;
-            if (cc[n] >= 0) {
-                const float fn = p.pf_new[cb[n] + (size_t)k * CELLS];
-                float fo = 0.0f;
-                if (blend || blend2) fo = p.pf_old[cb[n] + (size_t)k * CELLS];
-                fc[n] = blend_in_time(blend, fo, fn, tw);
-                if (TWO) fc2[n] = blend_in_time(blend2, fo, fn, tw2);
-            }
-        }
-#pragma unroll
-        for (int n = 1; n < 8; ++n)
-            if (cc[n] < 0) { fc[n] = fc[0]; fc2[n] = fc2[0]; }
-        const float cxf = (float)(k % 3 - 1), cyf = (float)((k / 3) % 3 - 1), czf = (float)(k / 9 - 1);
-        {
-            const float f_int = trilin(fc[0], fc[1], fc[2], fc[3], fc[4], fc[5], fc[6], fc[7], s.wx, s.wy, s.wz);
-            const float feq_int = calculate_equilibrium(m1.x, m1.y, m1.z, m1.w, w_k, cxf, cyf, czf);
-            const float f_neq = f_int - feq_int;
-            p.f_iface[out] = feq_int + f_neq * scale;
-        }
-        if (TWO) {
-            const float f_int = trilin(fc2[0], fc2[1], fc2[2], fc2[3], fc2[4], fc2[5], fc2[6], fc2[7], s.wx, s.wy, s.wz);
-            const float feq_int = calculate_equilibrium(m2.x, m2.y, m2.z, m2.w, w_k, cxf, cyf, czf);
-            const float f_neq = f_int - feq_int;
-            a.f_iface2[out] = feq_int + f_neq * scale;
-        }
-    }
-}
+// (Round 3 tried both passes in ONE kernel, one thread per source cell walking the populations pulled from it: nine dependent rounds
+// of loads per thread at 100 VGPRs - 97 us against 42 + 22 on the wing. profiles/r03_interface_pass_fused_experiment.txt; not kept.)
 
 // ---- Bouzidi correction, reference src/bouzidi_kernel.jl:13-92 ----
 struct BouzidiParams {

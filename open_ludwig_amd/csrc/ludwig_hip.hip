@@ -115,8 +115,6 @@ struct LudwigLevel {
     float4 *source_w[N_PARTS] = {};     // per source cell: interpolation weights wx, wy, wz
     float4 *source_mac[N_PARTS] = {};   // per source cell, rewritten every pass: interpolated rho, ux, uy, uz
     float4 *source_mac2[N_PARTS] = {};  // the same for the speculated weight of the next sub-step
-    IfaceSource *fused_src[N_PARTS] = {};   // the fused pass (k_interface_fused): one 64-B record per source cell ...
-    uint32_t *fused_outs[N_PARTS] = {};     // ... and one output position per link, grouped by source, ascending k
     float *f_iface2 = nullptr;
     // Interface values computed ahead for the second sub-step of a pair (reference src/solver_control.jl:63-83: the child
     // steps 2t with weight 0.0 and 2t+1 with 0.5 against the same parent buffers): valid while the parent was not written.
@@ -540,37 +538,13 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
             }
             links.push_back(make_int4(l.e.x, l.e.y, (int)weights.size() - 1, 0));
         }
-        // the fused pass: per source its record and the output positions of its links, ascending k
-        std::vector<IfaceSource> fsrc(weights.size());
-        std::vector<uint32_t> fouts(links.size());
-        {
-            if ((int64_t)L->n_iface_blocks * Q * CELLS >= ((int64_t)1 << 32)) return fail(LUDWIG_ERR_INVALID, "too many interface blocks for 32-bit positions");
-            std::vector<std::vector<std::pair<int, uint32_t>>> per((size_t)weights.size());
-            for (const int4 &l : links) {
-                const int k = l.y & 31, gbi = l.y >> 5, cell = l.x & 511;
-                per[(size_t)l.z].push_back({k, (uint32_t)(((size_t)k * L->n_iface_blocks + gbi) * CELLS + cell)});
-            }
-            uint32_t pos = 0;
-            for (size_t si = 0; si < per.size(); ++si) {
-                std::sort(per[si].begin(), per[si].end());
-                IfaceSource &r = fsrc[si];
-                r.c0 = corners[2 * si]; r.c1 = corners[2 * si + 1];
-                r.wx = weights[si].x; r.wy = weights[si].y; r.wz = weights[si].z;
-                r.mask = 0; r.first_out = pos; r.pad[0] = r.pad[1] = r.pad[2] = 0;
-                for (const auto &kv : per[si]) {
-                    if (r.mask >> kv.first & 1u) return fail(LUDWIG_ERR_STATE, "interface links: population %d pulled twice from one source cell", kv.first);
-                    r.mask |= 1u << kv.first;
-                    fouts[pos++] = kv.second;
-                }
-            }
-        }
         // launch order of the links: population by population, sources in (z, y, x) order inside. Neighbouring lanes then
         // read neighbouring parent cells of ONE population array (a few 128-B lines per wave-load instead of ~30) and
         // write neighbouring cells of f_iface.
         std::stable_sort(links.begin(), links.end(), [](const int4 &u, const int4 &v) { return (u.y & 31) < (v.y & 31); });
         L->ahead[a2].valid = false;
         void **owned[] = {(void **)&L->links[a2], (void **)&L->sources[a2], (void **)&L->source_w[a2], (void **)&L->source_mac[a2],
-                          (void **)&L->source_mac2[a2], (void **)&L->fused_src[a2], (void **)&L->fused_outs[a2]};
+                          (void **)&L->source_mac2[a2]};
         for (void **q : owned)
             if (*q) { (void)hipFree(*q); *q = nullptr; }
         L->n_links[a2] = (int)links.size();
@@ -584,10 +558,7 @@ int build_interface_links(LudwigLevel *L, const LudwigLevel *parent, int nx_g, i
             LW_HIP(hipMemcpy(L->source_w[a2], weights.data(), weights.size() * sizeof(float4), hipMemcpyHostToDevice));
             LW_HIP(hipMalloc((void **)&L->source_mac[a2], weights.size() * sizeof(float4)));
             LW_HIP(hipMalloc((void **)&L->source_mac2[a2], weights.size() * sizeof(float4)));
-            LW_HIP(hipMalloc((void **)&L->fused_src[a2], fsrc.size() * sizeof(IfaceSource)));
-            LW_HIP(hipMemcpy(L->fused_src[a2], fsrc.data(), fsrc.size() * sizeof(IfaceSource), hipMemcpyHostToDevice));
-            LW_HIP(hipMalloc((void **)&L->fused_outs[a2], fouts.size() * sizeof(uint32_t)));
-            LW_HIP(hipMemcpy(L->fused_outs[a2], fouts.data(), fouts.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+
         }
     }
     if (!L->f_iface && L->n_iface_blocks > 0) {
@@ -663,7 +634,6 @@ static int interface_launch(LudwigLevel *L, const LudwigLevel *parent, int part,
     // first sub-step of a pair (even t_sub): also produce the values for t_sub + 1 at weight 0.5
     const bool two = (t_sub % 2 == 0) && !parent->external_writer && getenv("LUDWIG_NO_IFACE_AHEAD") == nullptr;
     InterfaceArgs a{};
-    a.src = L->fused_src[part]; a.outs = L->fused_outs[part];
     a.corners = L->sources[part]; a.weights = L->source_w[part];
     a.mac = L->source_mac[part]; a.mac2 = L->source_mac2[part];
     a.links = L->links[part];
@@ -671,16 +641,7 @@ static int interface_launch(LudwigLevel *L, const LudwigLevel *parent, int part,
     a.tw2 = 0.5f;
     a.n_sources = L->n_sources[part]; a.n_links = L->n_links[part];
     const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
-    // LUDWIG_IFACE_FUSED=1: both passes in one kernel, one thread per source cell (experiment: slower, profiles/r03_interface_pass_fused_experiment.txt)
-    static const bool two_kernels = getenv("LUDWIG_IFACE_FUSED") == nullptr;
-    if (!two_kernels) {
-        if (two) hipLaunchKernelGGL(k_interface_fused<true>, gs, dim3(256), 0, st, p, a);
-        else hipLaunchKernelGGL(k_interface_fused<false>, gs, dim3(256), 0, st, p, a);
-        if (two) {
-            ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
-            ah.tw = a.tw2; ah.tau_parent = parent_tau; ah.use_temporal = p.use_temporal;
-        }
-    } else if (two) {
+    if (two) {
         hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, st, p, a);
         hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, st, p, a);
         ah.valid = true; ah.parent = parent; ah.parent_version = parent->version; ah.t_sub = t_sub + 1;
@@ -1011,8 +972,6 @@ void ludwig_level_destroy(LudwigLevel *L)
         if (L->source_w[a]) (void)hipFree(L->source_w[a]);
         if (L->source_mac[a]) (void)hipFree(L->source_mac[a]);
         if (L->source_mac2[a]) (void)hipFree(L->source_mac2[a]);
-        if (L->fused_src[a]) (void)hipFree(L->fused_src[a]);
-        if (L->fused_outs[a]) (void)hipFree(L->fused_outs[a]);
     }
     if (L->f_iface) (void)hipFree(L->f_iface);
     if (L->d_ref2int) (void)hipFree(L->d_ref2int);

@@ -887,7 +887,7 @@ class MultiLevelRunner:
 
     def __init__(self, grids: Sequence[BlockLevel], owners, params, rank: int, world: int, device: int,
                  stage_through_host: bool = False, overlap: bool = True, transport: Optional[str] = None, comm=None,
-                 wire_ranks: Optional[List[Dict[int, int]]] = None):
+                 wire_ranks: Optional[List[Dict[int, int]]] = None, requests_to_me: Optional[Callable] = None):
         import ctypes as C
         import torch
         from . import _lib
@@ -926,7 +926,10 @@ class MultiLevelRunner:
                 for name in ("f", "rho", "vel"):
                     needs[name] = np.unique(np.concatenate([needs[name], extra[name]]))
             mine = make_requests(v, g.n_blocks, needs)
-            to_me = exchange_requests(mine, world, rank) if world > 1 else {}
+            if requests_to_me is not None:          # loop-back tests: what the peers would ask, supplied by the caller (level index, own requests)
+                to_me = requests_to_me(i, mine)
+            else:
+                to_me = exchange_requests(mine, world, rank) if world > 1 else {}
             plan = build_plan(v, g.n_blocks, mine, to_me)
             plans.append(plan)
             # "boundary" part = owned blocks next to a ghost block (they read ghosts) AND owned blocks any peer reads from (same-level

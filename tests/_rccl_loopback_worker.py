@@ -71,6 +71,108 @@ def symmetric_brick_plan(grid, nb, upload_only=True, spheres=False):
     return view, partition.build_plan(view, n_global, mine, to_me), params
 
 
+def nested_symmetric_bricks(grid, nb):
+    """Two nested levels on a periodic box of grid[0] x 1 x 1 bricks of nb^3 level-1 blocks, every brick the same: the refined region is
+    the two layers of level-1 blocks on either side of every x-cut plane (whole y-z slabs), so every cut runs through level 2 -
+    same-level ghosts on both levels, exchanged in MultiLevelRunner's order around the part launches of a parent and a finest level.
+    (Parent-data ghosts do not occur: the slabs' faces lie two level-1 blocks inside the bricks.) Only x is cut, and the slabs are
+    whole in y and z, because the reference's domain-edge chain
+    (src/physics_kernels.jl:88-140) works on GLOBAL coordinates without wrap: a link whose source block is missing AND whose source
+    cell lies across the global edge takes the edge condition, and that must be the same links in the one-brick box as in the
+    G-brick box - with x-slabs no missing-source link comes near an edge in x, and the y / z extents of the two boxes are equal.
+    Returns the GLOBAL host levels, the per-level owners (brick of a block), the step parameters and, per level, the function that
+    maps the global element offsets a peer p would SEND to the same places of brick 0 (everything is periodic with one brick)."""
+    from open_ludwig_amd import cases
+    from open_ludwig_amd.physics import SolverParams
+    nb3 = (nb, nb, nb) if isinstance(nb, int) else tuple(nb)
+    assert grid[1] == 1 and grid[2] == 1, "the nested loop-back cuts x only (see the docstring)"
+    nbg = tuple(nb3[i] * grid[i] for i in range(3))
+    tau1 = 0.5006
+    l1 = cases.make_level(1, cases.full_box_coords(*nbg), nbg, tau1, periodic=(True, True, True), temporal=True)
+    near = lambda b, n: (b - 1) % n in (0, n - 1)              # level-1 block next to a cut plane
+    c2 = []
+    for (bx, by, bz) in l1.active_block_coords:
+        if near(bx, nb3[0]):
+            c2 += [(2 * bx - 1 + (d & 1), 2 * by - 1 + ((d >> 1) & 1), 2 * bz - 1 + ((d >> 2) & 1)) for d in range(8)]
+    l2 = cases.make_level(2, c2, tuple(2 * n for n in nbg), 0.5 + (tau1 - 0.5) / 2, periodic=(True, True, True), temporal=True)
+    cases.init_taylor_green(l1, tuple(8 * n for n in nb3), 0.03)        # period = one brick, on both levels
+    cases.init_taylor_green(l2, tuple(16 * n for n in nb3), 0.03)
+    grids = [l1, l2]
+    owners = []
+    for i, g in enumerate(grids):
+        c = (np.asarray(g.active_block_coords, dtype=np.int64) - 1) >> i           # level-1 block that contains it
+        owners.append(((c[:, 0] // nb3[0]) * grid[1] + c[:, 1] // nb3[1]) * grid[2] + c[:, 2] // nb3[2])
+    params = SolverParams(domain_nx=8 * nbg[0], domain_ny=8 * nbg[1], domain_nz=8 * nbg[2], wall_model_active=False, c_wale=0.5,
+                          nu_sgs_bg=0.0005, inlet_turbulence=0.0, use_temporal_interp=True, sponge_blend_dist=False)
+
+    def mapper(i):
+        g = grids[i]
+        coords = np.asarray(g.active_block_coords, dtype=np.int64)
+        dims = np.array(nbg) << i
+        lut = {tuple(c): j for j, c in enumerate(coords)}
+        n = g.n_blocks
+
+        def in_my_brick(goff, p):
+            shift = np.array([p // (grid[1] * grid[2]) * nb3[0], (p // grid[2]) % grid[1] * nb3[1], p % grid[2] * nb3[2]]) << i
+            comp, rem = np.divmod(goff, n * 512)
+            gblk, cell = np.divmod(rem, 512)
+            c0 = (coords[gblk] - 1 - shift) % dims + 1
+            g0 = np.array([lut[tuple(c)] for c in c0], dtype=np.int64)
+            return (comp * n + g0) * 512 + cell
+        return in_my_brick
+    return grids, owners, params, [mapper(0), mapper(1)]
+
+
+def nested_main(grid, nb, steps, out_path, transport):
+    """2-level loop-back: MultiLevelRunner as rank 0 of the brick decomposition, every peer wired to rank 0, against the single-device
+    run of the one-brick box with the same refined corners."""
+    from open_ludwig_amd import adapt, cases, execute_timestep_batch, partition
+    from oracle import oracle as _o          # buffer-parity helper only
+    from open_ludwig_amd.physics import SolverParams
+    grids, owners, params, maps = nested_symmetric_bricks(grid, nb)
+    if transport == "native":
+        os.environ["LUDWIG_HALO_SELF_VIA_RCCL"] = "1"
+    world_bricks = grid[0] * grid[1] * grid[2]
+
+    def to_me(i, mine):
+        return {p: {name: maps[i](a, p) for name, a in req.items()} for p, req in mine.items()}
+
+    wire = [{p: 0 for p in range(world_bricks)} for _ in grids]
+    runner = partition.MultiLevelRunner(grids, owners, params, 0, 1, 0, transport=transport, wire_ranks=wire, requests_to_me=to_me)
+    rep = {"backend": dist.get_backend(), "transport": transport, "nested": True, "grid": list(grid),
+           "blocks": [int(g.n_blocks) for g in grids], "owned": [int(v.n_owned) for v in runner.views],
+           "halo_bytes_per_level": [int(pl.bytes_per_step()) for pl in runner.plans],
+           "parent_data_in_level1_halo": bool(runner.plans[0].has("rho"))}
+    # ghosts of the start state, fetched the way every later one is
+    for i, ex in enumerate(runner.ex):
+        for fields in ({"f": "f", "vel": "vel"}, {"f": "f_temp", "vel": "vel_temp"}):
+            if runner.plans[i].has("rho"):
+                fields = dict(fields, rho="rho")
+            ex.post(fields); ex.join()
+    runner.synchronize()
+    for t in range(1, steps + 1):
+        runner.step(t)
+    runner.synchronize()
+    nb3 = (nb, nb, nb) if isinstance(nb, int) else tuple(nb)
+    one, _, params1, _ = nested_symmetric_bricks((1, 1, 1), nb3)
+    dev = [adapt(g, 0) for g in one]
+    execute_timestep_batch(dev, 1, steps, np.float32(0.0), params1)
+    same = {}
+    for i, (lv, v) in enumerate(zip(runner.levels, runner.views)):
+        fn, vn = _o.newest_buffers(i, steps)
+        pos = {tuple(c): j for j, c in enumerate(one[i].active_block_coords)}
+        sel = np.array([pos[tuple(c)] for c in np.asarray(v.level.active_block_coords)[: v.n_owned]])
+        for name in (fn, vn, "rho"):
+            same[f"level{i + 1}_{name}"] = bool(np.array_equal(lv.download(name)[:, :, :, : v.n_owned], dev[i].download(name)[:, :, :, sel]))
+        rep[f"moved{i + 1}"] = bool(lv.download(vn)[:, :, :, : v.n_owned].std() > 0)
+    rep["identical"] = same
+    for d in dev:
+        d.close()
+    json.dump(rep, open(out_path, "w"))
+    print(json.dumps(rep), flush=True)
+    runner.close(dist)
+
+
 def main():
     grid = tuple(int(v) for v in sys.argv[1].split("x"))
     nb = int(sys.argv[2]) if "," not in sys.argv[2] else tuple(int(v) for v in sys.argv[2].split(","))
@@ -84,6 +186,8 @@ def main():
     else:
         _p.init_rccl(0)
     rep = {"backend": dist.get_backend(), "world": dist.get_world_size(), "grid": list(grid), "blocks_per_brick_edge": nb, "steps": steps}
+    if "nested" in opts:
+        return nested_main(grid, nb, steps, out_path, os.environ.get("LOOPBACK_TRANSPORT", "native"))
 
     # the collectives of bench.py (all_reduce MAX, barrier) and case.DistributedStepper (all_reduce MIN, all_gather, gather_object)
     w = torch.tensor([1.5, 2.5], dtype=torch.float64, device="cuda")

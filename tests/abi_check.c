@@ -38,6 +38,11 @@ int main(int argc, char **argv)
     FIELD(LudwigLevelInfo, n_blocks); FIELD(LudwigLevelInfo, n_owned); FIELD(LudwigLevelInfo, n_fast_blocks); FIELD(LudwigLevelInfo, n_general_blocks);
     FIELD(LudwigLevelInfo, n_boundary_cells); FIELD(LudwigLevelInfo, has_temporal_storage); FIELD(LudwigLevelInfo, has_post_collision);
     FIELD(LudwigLevelInfo, n_xrun_blocks); FIELD(LudwigLevelInfo, device_bytes);
+    SIZE(LudwigHaloPlanDesc);
+    FIELD(LudwigHaloPlanDesc, n_peers); FIELD(LudwigHaloPlanDesc, peer_ranks); FIELD(LudwigHaloPlanDesc, send_count); FIELD(LudwigHaloPlanDesc, recv_count);
+    FIELD(LudwigHaloPlanDesc, send_index); FIELD(LudwigHaloPlanDesc, recv_index);
+    printf("enum LUDWIG_HALO_GROUPS %d\n", (int)LUDWIG_HALO_GROUPS);
+    printf("enum LUDWIG_UNIQUE_ID_BYTES %d\n", (int)LUDWIG_UNIQUE_ID_BYTES);
     printf("enum LUDWIG_FIELD_COUNT %d\n", (int)LUDWIG_FIELD_COUNT);
     printf("enum LUDWIG_WALL_DIST %d\n", (int)LUDWIG_WALL_DIST);
     printf("enum LUDWIG_PART_INTERIOR %d\n", (int)LUDWIG_PART_INTERIOR);

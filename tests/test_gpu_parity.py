@@ -411,8 +411,7 @@ def test_writes_through_a_raw_field_pointer_are_honoured(gpu):
 def test_reference_behaviour_switches_give_the_same_bits(gpu, tmp_path):
     """The three places where the library deliberately does something else than the reference's arrays suggest - its own block
     order in device memory, one HIP stream per level inside a batch, the elided rho store - each have a switch back
-    (LUDWIG_REFERENCE_BLOCK_ORDER, LUDWIG_BATCH_SERIAL, LUDWIG_EAGER_RHO), and the coarse -> fine interface pass has a fused
-    one-kernel form beside the two kernels (LUDWIG_IFACE_FUSED). With all of them set, in a fresh process, a 3-level
+    (LUDWIG_REFERENCE_BLOCK_ORDER, LUDWIG_BATCH_SERIAL, LUDWIG_EAGER_RHO). With all three set, in a fresh process, a 3-level
     wall-model tunnel gives exactly the fields of the default mode (and both equal the oracle's)."""
     import os
     import subprocess
@@ -426,7 +425,7 @@ def test_reference_behaviour_switches_give_the_same_bits(gpu, tmp_path):
             "execute_timestep_batch(d, 1, 5, np.float32(0.05), p)\\n"
             "np.savez(sys.argv[1], **{f'{n}{i}': x.download(n) for i, x in enumerate(d) for n in ('f', 'f_temp', 'vel', 'vel_temp', 'rho')})\\n" % root)
     out = str(tmp_path / "ref_mode.npz")
-    env = dict(os.environ, LUDWIG_REFERENCE_BLOCK_ORDER="1", LUDWIG_BATCH_SERIAL="1", LUDWIG_EAGER_RHO="1", LUDWIG_IFACE_FUSED="1")
+    env = dict(os.environ, LUDWIG_REFERENCE_BLOCK_ORDER="1", LUDWIG_BATCH_SERIAL="1", LUDWIG_EAGER_RHO="1")
     subprocess.run([sys.executable, "-c", code.replace("\\n", "\n"), out], check=True, env=env)
     ref = np.load(out)
     grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)

@@ -92,8 +92,11 @@ def _julia_struct_layout(text, name):
     body = re.search(r"^struct\s+" + name + r"\b(.*?)^end", text, flags=re.S | re.M).group(1)
     body = re.sub(r"#.*", "", body)
     fields, off, max_al = [], 0, 1
-    for fname, ftype in re.findall(r"(\w+)::([\w{}]+)", body):
+    for fname, ftype in re.findall(r"(\w+)::((?:NTuple\{\d+,\s*)?[\w{}]+)", body):
+        m = re.match(r"NTuple\{(\d+),\s*(.*)", ftype)                 # NTuple{N,T}: N elements of T inline, like a C array
+        count, ftype = (int(m.group(1)), m.group(2).rstrip("}")) if m else (1, ftype)
         size, al = (8, 8) if ftype.startswith("Ptr{") else _JULIA_TYPES[ftype]
+        size *= count
         off = (off + al - 1) // al * al
         fields.append((fname, off, size))
         off += size
@@ -125,20 +128,21 @@ def abi_report(tmp_path_factory):
 
 def test_header_is_c99_and_struct_layouts_match_ctypes(abi_report):
     pairs = {"LudwigLevelHost": _lib.LevelHost, "LudwigStepFlags": _lib.StepFlags, "LudwigSurfaceParams": _lib.SurfaceParams,
-             "LudwigLevelInfo": _lib.LevelInfo}
+             "LudwigLevelInfo": _lib.LevelInfo, "LudwigHaloPlanDesc": _lib.HaloPlanDesc}
     for cname, cls in pairs.items():
         assert abi_report["struct"][cname] == C.sizeof(cls), cname
         want = [(n, getattr(cls, n).offset, getattr(cls, n).size) for n, _ in cls._fields_]
         assert abi_report["field"][cname] == want, cname          # same names, same order, same offsets and sizes
     assert abi_report["enum"] == {"LUDWIG_FIELD_COUNT": len(_lib.FIELD_NAMES), "LUDWIG_WALL_DIST": _lib.WALL_DIST,
-                                  "LUDWIG_PART_INTERIOR": _lib.PART_INTERIOR}
+                                  "LUDWIG_PART_INTERIOR": _lib.PART_INTERIOR, "LUDWIG_HALO_GROUPS": len(_lib.HALO_GROUPS),
+                                  "LUDWIG_UNIQUE_ID_BYTES": _lib.UNIQUE_ID_BYTES}
 
 
 def test_julia_binding_structs_match_the_header(abi_report):
     """julia/LudwigHIP.jl cannot run here (no Julia in the image); its struct definitions are at least layout-checked
     against what gcc makes of the header, and every symbol it ccalls must be one the header declares."""
     text = open(os.path.join(ROOT, "julia", "LudwigHIP.jl")).read()
-    for jname, cname in (("LevelHost", "LudwigLevelHost"), ("StepFlags", "LudwigStepFlags")):
+    for jname, cname in (("LevelHost", "LudwigLevelHost"), ("StepFlags", "LudwigStepFlags"), ("HaloPlanDesc", "LudwigHaloPlanDesc")):
         fields, size = _julia_struct_layout(text, jname)
         assert fields == abi_report["field"][cname], jname
         assert size == abi_report["struct"][cname], jname
