@@ -140,12 +140,12 @@ def cpu_baseline(size: int, seconds: float):
             "sample": f"{size}^3 periodic box, same parameters, {steps} steps in {dt:.1f} s (CPU oracle, OpenMP)"}
 
 
-def workload_text(args, world, brick, rgrid, box) -> str:
+def workload_text(args, world, brick, rgrid, box, rehearsal: bool = False) -> str:
     base = "uniform periodic box, D3Q27 regularized-BGK + WALE, Taylor-Green start (SURVEY 8d C2)"
     if world == 1:
         return f"{base}; {box[0]}^3 cells on one GPU" + (" (strong-scaling base: BASELINE configs[3] on one GPU)" if args.scaling == "strong" else "")
     cut = (f"{world} bricks of {brick[0] * 8}x{brick[1] * 8}x{brick[2] * 8} cells in a {rgrid[0]}x{rgrid[1]}x{rgrid[2]} rank grid, "
-           "one-cell halo of f,u per step over RCCL")
+           "one-cell halo of f,u per step " + ("over gloo with host-staged messages (one-GPU rehearsal)" if rehearsal else "over RCCL"))
     if args.scaling == "strong":
         return f"{base}; STRONG scaling: fixed global box of {box[0]}x{box[1]}x{box[2]} cells (BASELINE configs[3] at --size 512), {cut}"
     return f"{base}; WEAK scaling: {args.size}^3 cells per GPU, global box {box[0]}x{box[1]}x{box[2]} cells, {cut}"
@@ -393,7 +393,7 @@ def main():
             "value": round(mlups, 1), "unit": "MLUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_text(args, world, brick, rgrid, box),
+            "config": {"workload": workload_text(args, world, brick, rgrid, box, rehearsal),
                        "scaling_mode": args.scaling, "global_box_cells": list(box),
                        "cells_per_gpu": cells_per_rank, "global_cells": total_cells, "tau": 0.5006, "c_wale": 0.5,
                        "nu_sgs_background": 0.0005, "launch_order": args.order or "library default",
