@@ -39,9 +39,6 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int N_PARTS = 3, N_CLASSES = 3;   // class 1 = blocks with a missing neighbour (GENERAL instantiation), 2 = all-neighbour blocks; 0 unused
-#ifndef LW_DEFAULT_SPLIT_STEP
-#define LW_DEFAULT_SPLIT_STEP 0
-#endif
 constexpr int XRUN = 4, XRUN_MAX = 4;       // waves per workgroup = blocks of an x-run (8 and 16 were tried in rounds 1-2: slower)
 
 }  // namespace
@@ -99,8 +96,7 @@ struct LudwigLevel {
     int32_t *items[N_PARTS][N_CLASSES] = {};
     int64_t n_items[N_PARTS][N_CLASSES] = {};
     // small levels step both kinds of blocks in ONE launch (merge_classes): the all-neighbour workgroups followed by the general ones,
-    // through the GENERAL instantiation. The separate lists stay: a sub-step that has an interface pass to wait for steps the
-    // all-neighbour blocks first, under that pass (launch_stream_collide "split").
+    // through the GENERAL instantiation. The separate lists stay for the rho replay and for levels that are not merged.
     int32_t *items_merged[N_PARTS] = {};
     int64_t n_items_merged[N_PARTS] = {};
     int n_fast_blocks = 0;
@@ -146,8 +142,6 @@ struct LudwigLevel {
     int64_t step_count = 0, last_step_t = -1, last_replay_step = -10;   // a level asked for rho after two steps in a row turns eager
     // ludwig_execute_timestep_batch runs every level on a stream of its own (level_streams below): events that order them
     hipStream_t own_stream = nullptr;
-    hipStream_t side_stream = nullptr;  // the interface pass of a split sub-step (same priority as own_stream)
-    hipEvent_t ev_fork = nullptr, ev_iface = nullptr;
     hipEvent_t parent_wait = nullptr;   // set by recursive_step: the parent's step this sub-step's interface pass has to wait for
     hipEvent_t ev_stepped = nullptr;    // recorded on this level's stream after each of its steps (collision + Bouzidi)
     hipEvent_t ev_consumed = nullptr;   // recorded on the CHILD's stream once its interface pass has read this level's buffers
@@ -790,35 +784,10 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         const int r = interface_decide(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, &istate);
         if (r) return r;
     }
-    // Split sub-step (level streams only; an experiment kept behind LUDWIG_SPLIT_STEP, default 0 = off). The interface pass is the one
-    // piece of a sub-step that reads the PARENT, and only the blocks with a missing neighbour read its result; the all-neighbour
-    // blocks depend on nothing but this level's previous sub-step. Mode 1: when the pass has to run (first sub-step of a pair), step the
-    // all-neighbour blocks FIRST - before this stream waits for the parent's step - then the wait, the pass and the general blocks.
-    // Mode 2: the pass on a side stream, under the all-neighbour blocks. Measured (profiles/r03_split_substep_ab.txt): mode 1 LOSES
-    // 1-6 % (two launches instead of the merged one cost more than the earlier start gains); mode 2 HALVES the speed of every
-    // multi-level case (3-level sphere 0.337 -> 0.665 ms per coarse step, wing 0.83 -> 1.08): HIP serves the streams of one priority from a
-    // small pool of hardware queues, the side stream lands in the queue of a level's own stream, and its wait for the parent then
-    // blocks that level's launches too (the lesson of round 2's RCCL traces, again).
-    static const int split_mode = [] { const char *e = getenv("LUDWIG_SPLIT_STEP"); return e ? atoi(e) : LW_DEFAULT_SPLIT_STEP; }();
-    const bool split = split_mode > 0 && istate == IFACE_LAUNCH && part == LUDWIG_PART_ALL && L->own_stream && L->stream == L->own_stream &&
-                       L->n_items[part][1] > 0 && L->n_items[part][2] > 0 && (split_mode == 1 || L->side_stream);
-    if (split && split_mode == 1) {
-        int r;
-        if ((r = launch_list(L->items[part][2], L->n_items[part][2], false))) return r;
-        if (parent_wait) LW_HIP(hipStreamWaitEvent(cs, parent_wait, 0));
-        if ((r = interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, cs))) return r;
-        if ((r = launch_list(L->items[part][1], L->n_items[part][1], true))) return r;
-    } else if (split) {
-        LW_HIP(hipEventRecord(L->ev_fork, cs));               // the pass rewrites side buffers the previous sub-step's launch read
-        LW_HIP(hipStreamWaitEvent(L->side_stream, L->ev_fork, 0));
-        if (parent_wait) LW_HIP(hipStreamWaitEvent(L->side_stream, parent_wait, 0));
-        int r = interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, L->side_stream);
-        if (r) return r;
-        LW_HIP(hipEventRecord(L->ev_iface, L->side_stream));
-        if ((r = launch_list(L->items[part][2], L->n_items[part][2], false))) return r;
-        LW_HIP(hipStreamWaitEvent(cs, L->ev_iface, 0));
-        if ((r = launch_list(L->items[part][1], L->n_items[part][1], true))) return r;
-    } else {
+    // (Round 3 tried to take the interface pass - the one piece of a sub-step that reads the PARENT, and whose result only the general
+    // blocks read - off the chain: all-neighbour blocks first, before the wait for the parent's step; and the pass on a side stream
+    // under them. Both measured slower than this merged launch, at any stream priority: profiles/r03_split_substep_ab.txt. Removed.)
+    {
         if (parent_wait) LW_HIP(hipStreamWaitEvent(cs, parent_wait, 0));
         int r;
         if (istate == IFACE_LAUNCH && (r = interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, false, cs))) return r;
@@ -977,9 +946,6 @@ void ludwig_level_destroy(LudwigLevel *L)
     if (L->d_ref2int) (void)hipFree(L->d_ref2int);
     if (L->scratch) (void)hipFree(L->scratch);
     if (L->own_stream) (void)hipStreamDestroy(L->own_stream);
-    if (L->side_stream) (void)hipStreamDestroy(L->side_stream);
-    if (L->ev_fork) (void)hipEventDestroy(L->ev_fork);
-    if (L->ev_iface) (void)hipEventDestroy(L->ev_iface);
     if (L->ev_stepped) (void)hipEventDestroy(L->ev_stepped);
     if (L->ev_consumed) (void)hipEventDestroy(L->ev_consumed);
     if (L->bouzidi_links) (void)hipFree(L->bouzidi_links);
@@ -1526,7 +1492,7 @@ static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-
         // every event operation costs the stream ~7 us between two kernels (kernel trace of the 3-level sphere): wait for a
         // parent step once, not once per sub-step
         // the only reader of the parent is this level's interface pass: the wait for the parent's step goes where that pass goes
-        // (launch_stream_collide: this stream, or the side stream of a split sub-step) - unless the pass is hoisted below
+        // (launch_stream_collide) - unless the pass is hoisted below
         const bool need_parent = parent && (L->waited_parent != parent || L->waited_gen != parent->stepped_gen);
         bool hoisting = false;
         if (has_children && L->ev_consumed_set) {
@@ -1534,7 +1500,7 @@ static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-
             hoisting = he0 ? atoi(he0) != 0 : 20 * (int64_t)L->n_blocks >= 9 * (int64_t)levels[lvl]->n_blocks;
         }
         if (need_parent) {
-            // handed to launch_stream_collide, which waits where the interface pass goes (at once unless the sub-step is split)
+            // handed to launch_stream_collide, which waits right before the interface pass
             if (hoisting) LW_HIP(hipStreamWaitEvent(L->stream, parent->ev_stepped, 0));
             else L->parent_wait = parent->ev_stepped;
             L->waited_parent = parent; L->waited_gen = parent->stepped_gen;
@@ -1589,27 +1555,21 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
         hipError_t e = hipSuccess;
         for (int i = 0; i < n_levels && e == hipSuccess; ++i) {
             LudwigLevel *L = levels[i];
-            const char *sse = getenv("LUDWIG_SPLIT_STEP");
-            const bool want_side = i > 0 && sse && atoi(sse) == 2;      // the side-stream experiment (launch_stream_collide "split")
-            if (L->own_stream && (L->side_stream || !want_side) && L->ev_stepped && L->ev_consumed && L->ev_fork && L->ev_iface) continue;
+            if (L->own_stream && L->ev_stepped && L->ev_consumed) continue;
             // the finest level is the critical chain (2^(n-1) sub-steps per coarse step): its stream gets the highest priority, the
             // coarser levels fill what it leaves free (graded priorities: no better)
             const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);
             if (!L->own_stream) e = hipStreamCreateWithPriority(&L->own_stream, hipStreamNonBlocking, pr);
-            if (e == hipSuccess && !L->side_stream && want_side) e = hipStreamCreateWithPriority(&L->side_stream, hipStreamNonBlocking, pr);
             if (e == hipSuccess && !L->ev_stepped) e = hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming);
             if (e == hipSuccess && !L->ev_consumed) e = hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming);
-            if (e == hipSuccess && !L->ev_fork) e = hipEventCreateWithFlags(&L->ev_fork, hipEventDisableTiming);
-            if (e == hipSuccess && !L->ev_iface) e = hipEventCreateWithFlags(&L->ev_iface, hipEventDisableTiming);
         }
         if (e != hipSuccess) {
             for (int i = 0; i < n_levels; ++i) {
                 LudwigLevel *L = levels[i];
-                if (L->own_stream && L->ev_stepped && L->ev_consumed && L->ev_fork && L->ev_iface) continue;      // complete from an earlier batch: keep
-                hipEvent_t *evs[] = {&L->ev_stepped, &L->ev_consumed, &L->ev_fork, &L->ev_iface};
+                if (L->own_stream && L->ev_stepped && L->ev_consumed) continue;      // complete from an earlier batch: keep
+                hipEvent_t *evs[] = {&L->ev_stepped, &L->ev_consumed};
                 for (hipEvent_t *ev : evs)
                     if (*ev) { (void)hipEventDestroy(*ev); *ev = nullptr; }
-                if (L->side_stream) { (void)hipStreamDestroy(L->side_stream); L->side_stream = nullptr; }
                 if (L->own_stream) { (void)hipStreamDestroy(L->own_stream); L->own_stream = nullptr; }
             }
             return fail(LUDWIG_ERR_HIP, "batch: level streams: %s", hipGetErrorString(e));
