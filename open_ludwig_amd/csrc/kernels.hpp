@@ -703,8 +703,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((WIDE &
             fs[k] = l.x7 ? edge : inner;
         }
     });
+    // merged launches run all-neighbour blocks through the GENERAL instantiation too: nothing to patch there (wave-uniform flag)
+    const bool needs_patch = GENERAL && (flags & FLAG_ALL_NEIGHBOURS) == 0;
     if constexpr (RHO_ONLY) {
-        if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, z, own, fs);
+        if constexpr (GENERAL) { if (needs_patch) patch_missing_sources(p, meta, nbr, l, z, own, fs); }
         finish_rho_only(p, flags, own, fs);
         return;
     }
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu((WIDE &
         uN[c] = l.y7 ? uy_edge[c] : n_in;
         uS[c] = l.y0 ? uy_edge[c] : s_in;
     }
-    if constexpr (GENERAL) patch_missing_sources(p, meta, nbr, l, z, own, fs);
+    if constexpr (GENERAL) { if (needs_patch) patch_missing_sources(p, meta, nbr, l, z, own, fs); }
     finish_cell<POST, WALL>(p, flags, own, fs, uE[0], uE[1], uE[2], uW[0], uW[1], uW[2], uN[0], uN[1], uN[2], uS[0], uS[1], uS[2],
                             uT[0], uT[1], uT[2], uB[0], uB[1], uB[2]);
 }

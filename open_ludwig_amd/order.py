@@ -79,7 +79,8 @@ def plane_per_xcd_rot(coords, px: int = 4, py: int = 1, sweep: str = "zxy", rot:
 
 
 def plane_per_xcd_rot_w8(coords, px: int = 4, py: int = 2, sweep: str = "yxz") -> np.ndarray:
-    """For LUDWIG_XRUN=8 (8 waves per workgroup): a workgroup = one plane of a px x py patch of blocks (px * py = 8), rows
+    """Written for the 8-wave workgroups of rounds 1-2 (removed in round 3: slower; the library now groups any list by 4, so these
+    stay valid orders for tools/order_sweep.py): a workgroup = one plane of a px x py patch of blocks (px * py = 8), rows
     of x-consecutive blocks one after the other, so x neighbours sit in neighbouring waves (face column through LDS) and the
     y neighbour's plane is loaded by a wave of the same workgroup (its lines are in the CU's L1 when the face row is read).
     Plane z of a patch at block-z bz goes to XCD (z + bz) % 8 as in plane_per_xcd_rot."""
@@ -103,7 +104,7 @@ def plane_per_xcd_rot_w8(coords, px: int = 4, py: int = 2, sweep: str = "yxz") -
 
 
 def brick(coords, px: int, py: int, pz: int, rotate: bool = True) -> np.ndarray:
-    """Workgroup = px x-adjacent blocks x py y-adjacent blocks x pz consecutive planes (px * py * pz = LUDWIG_XRUN waves), waves
+    """Workgroup = px x-adjacent blocks x py y-adjacent blocks x pz consecutive planes (px * py * pz = 4 waves for the library to keep the group), waves
     ordered x fastest (same-plane x neighbours in neighbouring waves -> LDS column exchange); blocks visited in MEMORY order (bz
     fastest, then by, then bx) so that every population stream is read and written sequentially; the 8 / pz plane groups of a
     brick are consecutive workgroups, rotated with bz. Full boxes whose extents divide by px, py only (bench / tools)."""

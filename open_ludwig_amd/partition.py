@@ -495,7 +495,8 @@ class TorchHalo:
 def native_comm(device: int):
     """A LudwigComm over the ranks of the default torch.distributed group: rank 0 draws the RCCL unique id (ludwig_comm_unique_id),
     the 128 bytes travel through the process group the ranks already share, every rank joins (ludwig_comm_create). Returns the
-    handle (a ctypes.c_void_p); None when torch.distributed is not initialised (single process: every peer is this rank)."""
+    handle (a ctypes.c_void_p); None when torch.distributed is not initialised (single process: every peer is this rank).
+    Raises LudwigError on EVERY rank when any rank could not come up (the ranks agree on the outcome before anybody proceeds)."""
     import ctypes as C
     import torch.distributed as dist
     from . import _lib
@@ -506,11 +507,21 @@ def native_comm(device: int):
     box = [None]
     if rank == 0:
         buf = (C.c_char * _lib.UNIQUE_ID_BYTES)()
-        _lib.check(lib.ludwig_comm_unique_id(buf))
-        box[0] = bytes(buf)
+        rc = lib.ludwig_comm_unique_id(buf)
+        box[0] = bytes(buf) if rc == 0 else ("error", (lib.ludwig_last_error() or b"").decode("utf-8", "replace"))
     dist.broadcast_object_list(box, src=0)
+    if isinstance(box[0], tuple):
+        raise _lib.LudwigError(-5, "rank 0 could not draw an RCCL unique id: " + box[0][1])
     h = C.c_void_p()
-    _lib.check(lib.ludwig_comm_create(box[0], rank, world, int(device), C.byref(h)))
+    rc = lib.ludwig_comm_create(box[0], rank, world, int(device), C.byref(h))
+    msg = (lib.ludwig_last_error() or b"").decode("utf-8", "replace") if rc else ""
+    oks = [None] * world
+    dist.all_gather_object(oks, (rc, msg))
+    bad = [(r, m) for r, (c, m) in enumerate(oks) if c != 0]
+    if bad:
+        if rc == 0:
+            lib.ludwig_comm_destroy(h)
+        raise _lib.LudwigError(bad[0][1] and -2 or -2, f"ludwig_comm_create failed on rank(s) {[r for r, _ in bad]}: {bad[0][1]}")
     return h
 
 
@@ -625,8 +636,16 @@ class DistributedLevelRunner:
         self.comm, self._own_comm = comm, False
         if self.transport == "native":
             if self.comm is None:
-                self.comm = native_comm(device)
-                self._own_comm = self.comm is not None
+                try:
+                    self.comm = native_comm(device)
+                    self._own_comm = self.comm is not None
+                except _lib.LudwigError as e:
+                    # the library could not bring up its own RCCL communicator (no librccl to resolve, ncclCommInitRank refused):
+                    # the same exchange over the RCCL communicator torch.distributed already holds - said loudly, never silently
+                    import sys
+                    print(f"[ludwig] native RCCL communicator unavailable ({e}); halo exchange falls back to torch.distributed", file=sys.stderr, flush=True)
+                    self.transport = "torch"
+        if self.transport == "native":
             self.ex = NativeHalo(plan, self.level, self.comm, wire_rank)
             self.s_comm = None
         else:
@@ -958,8 +977,14 @@ class MultiLevelRunner:
         if self.transport == "native":
             # RCCL called from the library (NativeHalo): every level's plan has its own high-priority stream; one communicator
             if self.comm is None:
-                self.comm = native_comm(device)
-                self._own_comm = self.comm is not None
+                try:
+                    self.comm = native_comm(device)
+                    self._own_comm = self.comm is not None
+                except _lib.LudwigError as e:
+                    import sys
+                    print(f"[ludwig] native RCCL communicator unavailable ({e}); halo exchange falls back to torch.distributed", file=sys.stderr, flush=True)
+                    self.transport = "torch"
+        if self.transport == "native":
             for i, plan in enumerate(plans):
                 if self.levels[i] is None:
                     assert not plan.peers, "a level without a local copy exchanges nothing"

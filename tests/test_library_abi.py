@@ -158,3 +158,23 @@ def test_c_caller_through_dlopen(abi_report):
     assert c["level_create_null"] == "-1 out_cleared"
     assert "null" in c["last_error"]
     assert c["level_create_bad"] == "-1" and c["level_info_null"] == "-1"
+
+
+def test_multi_gpu_entry_points_reject_bad_arguments_without_a_device():
+    """The communicator / halo-plan entry points (include/ludwig_hip.h "multi-GPU") answer argument errors with a code and a message,
+    touch no GPU and load no RCCL doing so."""
+    lib = _lib.load()
+    out = C.c_void_p(1)
+    assert lib.ludwig_comm_unique_id(None) == -1 and b"null" in lib.ludwig_last_error()
+    assert lib.ludwig_comm_create(None, 0, 1, 0, C.byref(out)) == -1 and out.value is None          # the out pointer is cleared first
+    ident = (C.c_char * _lib.UNIQUE_ID_BYTES)()
+    assert lib.ludwig_comm_create(ident, 2, 2, 0, C.byref(out)) == -1                               # rank outside the world
+    d = _lib.HaloPlanDesc()
+    assert lib.ludwig_halo_plan_create(None, None, C.byref(d), C.byref(out)) == -1 and out.value is None
+    assert lib.ludwig_halo_exchange(None, 0, None, None) == -1
+    assert lib.ludwig_halo_wait(None) == -1
+    assert lib.ludwig_step_distributed(None, None, None, 1, 0.0, 0.5, 0.0, None) == -1
+    assert lib.ludwig_comm_allreduce_f32(None, None, 1, 0) == -1
+    assert lib.ludwig_level_field_layout(None, 0, None, None, None) == -1
+    lib.ludwig_comm_destroy(None)
+    lib.ludwig_halo_plan_destroy(None)                                                               # destroying nothing is a no-op
