@@ -143,6 +143,21 @@ struct LudwigLevel {
     // ludwig_execute_timestep_batch runs every level on a stream of its own (level_streams below): events that order them
     hipStream_t own_stream = nullptr;
     hipEvent_t parent_wait = nullptr;   // set by recursive_step: the parent's step this sub-step's interface pass has to wait for
+    // Parent-side interface pass (level streams, recursive_step): the PARENT's stream computes this level's interface values for
+    // the pair of sub-steps 2t, 2t + 1 right after the parent's step t, into set t & 1 of a second pair of side buffers - while this
+    // level is still stepping pair t - 1 out of the other set. This level's own stream then carries no interface kernels at all.
+    float *f_iface_b = nullptr, *f_iface2_b = nullptr;             // set 1 (set 0 = f_iface, f_iface2)
+    float4 *mac_b = nullptr, *mac2_b = nullptr;                    // scratch of set 1's pass (LUDWIG_PART_ALL)
+    struct PairReady {
+        bool valid = false;
+        const LudwigLevel *parent = nullptr;
+        uint64_t parent_version = 0;
+        int64_t pair = -1;                                         // t_sub >> 1 of the sub-steps the values are for
+        float tau_parent = 0.0f;
+        int use_temporal = 0, set = 0;
+    } pair_ready;
+    hipEvent_t ev_pair_done[2] = {nullptr, nullptr};               // recorded on THIS level's stream after the second sub-step of a pair
+    bool pair_done_set[2] = {false, false};
     hipEvent_t ev_stepped = nullptr;    // recorded on this level's stream after each of its steps (collision + Bouzidi)
     hipEvent_t ev_consumed = nullptr;   // recorded on the CHILD's stream once its interface pass has read this level's buffers
     bool ev_consumed_set = false;
@@ -600,6 +615,17 @@ static int interface_decide(LudwigLevel *L, const LudwigLevel *parent, int part,
     p.f_iface = L->f_iface;
     p.n_iface_blocks = L->n_iface_blocks;
     if (L->n_links[part] == 0) return LUDWIG_OK;
+    {   // values the parent's stream has produced for this pair of sub-steps (recursive_step: parent-side interface pass)
+        const LudwigLevel::PairReady &pr = L->pair_ready;
+        if (!ahead_of_step && part == LUDWIG_PART_ALL && pr.valid && pr.parent == parent && pr.parent_version == parent->version &&
+            pr.pair == (t_sub >> 1) && pr.tau_parent == parent_tau && pr.use_temporal == p.use_temporal &&
+            temporal_weight == ((t_sub & 1) ? 0.5f : 0.0f)) {
+            float *const first = pr.set ? L->f_iface_b : L->f_iface, *const second = pr.set ? L->f_iface2_b : L->f_iface2;
+            p.f_iface = (t_sub & 1) ? second : first;
+            *state = IFACE_READY;
+            return LUDWIG_OK;
+        }
+    }
     LudwigLevel::IfaceAhead &pre = L->prepared[part];
     const bool ready = pre.valid && pre.parent == parent && pre.parent_version == parent->version && pre.t_sub == t_sub &&
                        pre.tw == temporal_weight && pre.tau_parent == parent_tau && pre.use_temporal == p.use_temporal;
@@ -665,6 +691,61 @@ static int interface_pass(LudwigLevel *L, const LudwigLevel *parent, int part, S
     const int r = interface_decide(L, parent, part, p, t_sub, parent_tau, temporal_weight, ahead_of_step, &state);
     if (r || state != IFACE_LAUNCH) return r;
     return interface_launch(L, parent, part, p, t_sub, parent_tau, temporal_weight, ahead_of_step, L->stream);
+}
+
+// Parent-side interface pass: `parent` has just stepped t_pair on ITS stream; the interface values its child C needs for sub-steps
+// 2 t_pair (temporal weight 0.0) and 2 t_pair + 1 (0.5) are computed right there, behind that step, into set t_pair & 1 of C's side
+// buffers. C's stream, the critical chain of a nested case, then runs nothing but stream-collide and Bouzidi launches; the pass
+// shares the parent's (low-priority) stream with the parent's own kernels and fills the gaps the finest level leaves.
+// Dependencies: the pass reads the parent's new and saved state - same stream, right after the step that made them, before the
+// next one that overwrites them (the ev_consumed hand-shake of the child-side pass is not needed); it overwrites the set C read
+// two pairs ago - waited for through C's ev_pair_done. Same kernels, same arguments as the child-side pass: same bits.
+static int interface_pass_for_child(LudwigLevel *parent, LudwigLevel *C, int64_t t_pair, const LudwigStepFlags *fl)
+{
+    if (C->n_blocks == 0 || C->n_items[LUDWIG_PART_ALL][1] == 0 || parent->external_writer) return LUDWIG_OK;
+    SCParams p{};
+    const int64_t t_sub = 2 * t_pair;
+    fill_parent_params(p, parent, t_sub);
+    p.tau = C->tau;
+    p.tau_parent = parent->tau;
+    p.temporal_weight = 0.0f;
+    const int scale = 1 << (C->level_id - 1);
+    p.nx_g = fl->domain_nx * scale; p.ny_g = fl->domain_ny * scale; p.nz_g = fl->domain_nz * scale;
+    p.use_temporal = (fl->use_temporal_interp && parent->has_temporal) ? 1 : 0;
+    int rc = build_interface_links(C, parent, p.nx_g, p.ny_g, p.nz_g);
+    if (rc) return rc;
+    const int part = LUDWIG_PART_ALL;
+    if (C->n_links[part] == 0) return LUDWIG_OK;
+    const int set = (int)(t_pair & 1);
+    const size_t n_side = (size_t)C->n_iface_blocks * CELLS * Q, n_src = (size_t)C->n_sources[part];
+    if (!C->f_iface_b) {
+        LW_HIP(hipMalloc((void **)&C->f_iface_b, n_side * sizeof(float)));
+        LW_HIP(hipMalloc((void **)&C->f_iface2_b, n_side * sizeof(float)));
+        LW_HIP(hipMalloc((void **)&C->mac_b, n_src * sizeof(float4)));
+        LW_HIP(hipMalloc((void **)&C->mac2_b, n_src * sizeof(float4)));
+        C->device_bytes += (int64_t)(2 * n_side * sizeof(float) + 2 * n_src * sizeof(float4));
+        for (hipEvent_t &ev : C->ev_pair_done) LW_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    if (C->pair_done_set[set]) LW_HIP(hipStreamWaitEvent(parent->stream, C->ev_pair_done[set], 0));      // C has finished with this set
+    p.f_iface = set ? C->f_iface_b : C->f_iface;
+    p.n_iface_blocks = C->n_iface_blocks;
+    InterfaceArgs a{};
+    a.corners = C->sources[part]; a.weights = C->source_w[part];
+    a.mac = set ? C->mac_b : C->source_mac[part]; a.mac2 = set ? C->mac2_b : C->source_mac2[part];
+    a.links = C->links[part];
+    a.f_iface2 = set ? C->f_iface2_b : C->f_iface2;
+    a.tw2 = 0.5f;
+    a.n_sources = C->n_sources[part]; a.n_links = C->n_links[part];
+    const dim3 gs((unsigned)((a.n_sources + 255) / 256)), gl((unsigned)((a.n_links + 255) / 256));
+    hipLaunchKernelGGL(k_interface_sources<true>, gs, dim3(256), 0, parent->stream, p, a);
+    hipLaunchKernelGGL(k_interface_links<true>, gl, dim3(256), 0, parent->stream, p, a);
+    LW_HIP(hipGetLastError());
+    LudwigLevel::PairReady &pr = C->pair_ready;
+    pr.valid = true; pr.parent = parent; pr.parent_version = parent->version; pr.pair = t_pair;
+    pr.tau_parent = parent->tau; pr.use_temporal = p.use_temporal; pr.set = set;
+    C->ahead[part].valid = false;          // the child-side look-ahead buffers (set 0's second half) are about to be / have been reused
+    C->prepared[part].valid = false;
+    return LUDWIG_OK;
 }
 
 // The interface pass of sub-step t_sub, launched before the step itself. It reads the PARENT's buffers and writes this level's
@@ -950,6 +1031,13 @@ void ludwig_level_destroy(LudwigLevel *L)
     if (L->ev_consumed) (void)hipEventDestroy(L->ev_consumed);
     if (L->bouzidi_links) (void)hipFree(L->bouzidi_links);
     if (L->f_iface2) (void)hipFree(L->f_iface2);
+    {
+        void *more[] = {L->f_iface_b, L->f_iface2_b, L->mac_b, L->mac2_b};
+        for (void *q : more)
+            if (q) (void)hipFree(q);
+        for (hipEvent_t ev : L->ev_pair_done)
+            if (ev) (void)hipEventDestroy(ev);
+    }
     delete L;
 }
 
@@ -1521,7 +1609,15 @@ static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-
     if (has_children && fl->use_temporal_interp && L->has_temporal)
         if ((rc = ludwig_save_old(L, t_sub))) return rc;
     if ((rc = ludwig_step(L, parent, t_sub, u_vel, parent_tau, temporal_weight, fl))) return rc;
+    static const bool parent_side = getenv("LUDWIG_CHILD_SIDE_IFACE") == nullptr;      // LUDWIG_CHILD_SIDE_IFACE=1: round 2's placement
+    if (concurrent && parent && parent_side && (t_sub & 1) && L->ev_pair_done[0]) {
+        // this level has read the last of set (t_sub >> 1) & 1 of its interface values: the parent's stream may overwrite it
+        const int set = (int)((t_sub >> 1) & 1);
+        LW_HIP(hipEventRecord(L->ev_pair_done[set], L->stream));
+        L->pair_done_set[set] = true;
+    }
     if (concurrent && has_children) {
+        if (parent_side && (rc = interface_pass_for_child(L, levels[lvl], t_sub, fl))) return rc;
         LW_HIP(hipEventRecord(L->ev_stepped, L->stream));
         ++L->stepped_gen;
     }
@@ -1558,7 +1654,10 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
             if (L->own_stream && L->ev_stepped && L->ev_consumed) continue;
             // the finest level is the critical chain (2^(n-1) sub-steps per coarse step): its stream gets the highest priority, the
             // coarser levels fill what it leaves free (graded priorities: no better)
-            const int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);
+            // LUDWIG_LEVEL_STREAM_PRIORITY=2: graded - the finest level highest, its parent (whose stream carries the finest level's interface
+            // pass since round 3) one below, the rest lowest
+            int pr = !use_pr ? pr_least : (i == n_levels - 1 ? pr_greatest : pr_least);
+            if (pe && atoi(pe) == 2) pr = std::min(pr_least, pr_greatest + (n_levels - 1 - i));
             if (!L->own_stream) e = hipStreamCreateWithPriority(&L->own_stream, hipStreamNonBlocking, pr);
             if (e == hipSuccess && !L->ev_stepped) e = hipEventCreateWithFlags(&L->ev_stepped, hipEventDisableTiming);
             if (e == hipSuccess && !L->ev_consumed) e = hipEventCreateWithFlags(&L->ev_consumed, hipEventDisableTiming);
@@ -1581,6 +1680,8 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
             L->ev_consumed_set = false;
             L->waited_parent = nullptr;
             L->parent_wait = nullptr;
+            L->pair_ready.valid = false;
+            L->pair_done_set[0] = L->pair_done_set[1] = false;      // the previous batch ended with every stream idle
             L->stream = L->own_stream;
         }
         for (int i = 0; i + 1 < n_levels; ++i) {
