@@ -54,6 +54,9 @@ struct SCParams {
     // 0: this launch leaves `rho` unwritten - nobody reads it before the level's next step unless asked, and then
     // k_stream_collide_xrun<.., RHO_ONLY> recomputes it from the same inputs (ludwig_hip.hip "lazy rho")
     int32_t store_rho;
+    // non-null: copy_to_old!'s rho part fused into this launch - every cell saves its old rho here before storing the new one
+    // (whole-level launches of a level without ghost blocks only; ludwig_hip.hip "rho_old in the step")
+    float *rho_old_save;
 };
 
 template <int K, int N, class F>
@@ -325,6 +328,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
         st_f32(p.vel_out, own.b, V_BLOCK_BYTES, own.cell4, 0.0f);
         st_f32(p.vel_out, own.b, V_BLOCK_BYTES, COMP_BYTES + own.cell4, 0.0f);
         st_f32(p.vel_out, own.b, V_BLOCK_BYTES, 2 * COMP_BYTES + own.cell4, 0.0f);
+        if (p.rho_old_save) st_f32(p.rho_old_save, own.b, S_BLOCK_BYTES, own.cell4, ld_own(p.rho, own.b, S_BLOCK_BYTES, own.cell4));
         if (p.store_rho) st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, 1.0f);
         static_for<0, Q>([&](auto kc) {
             constexpr int k = decltype(kc)::value;
@@ -382,6 +386,7 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     st_f32(p.vel_out, own.b, V_BLOCK_BYTES, own.cell4, ux);
     st_f32(p.vel_out, own.b, V_BLOCK_BYTES, COMP_BYTES + own.cell4, uy);
     st_f32(p.vel_out, own.b, V_BLOCK_BYTES, 2 * COMP_BYTES + own.cell4, uz);
+    if (p.rho_old_save) st_f32(p.rho_old_save, own.b, S_BLOCK_BYTES, own.cell4, ld_own(p.rho, own.b, S_BLOCK_BYTES, own.cell4));
     if (p.store_rho) st_f32(p.rho, own.b, S_BLOCK_BYTES, own.cell4, rho);
 
     // ---- WALE eddy viscosity from the previous step's velocity, reference :251-300 ----

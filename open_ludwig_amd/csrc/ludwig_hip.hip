@@ -143,6 +143,11 @@ struct LudwigLevel {
     // ludwig_execute_timestep_batch runs every level on a stream of its own (level_streams below): events that order them
     hipStream_t own_stream = nullptr;
     hipEvent_t parent_wait = nullptr;   // set by recursive_step: the parent's step this sub-step's interface pass has to wait for
+    // rho_old in the step: copy_to_old!'s copy of rho (the one field a step overwrites in place) costs a launch and two transitions on
+    // a parent level's stream per step. The batch driver leaves it to the step that follows: every cell saves its old rho before it
+    // stores the new one (kernels.hpp rho_old_save). Only whole-level launches of a level without ghost blocks; anything that
+    // would read rho_old or write rho in between performs the copy first (resolve_rho_old).
+    bool rho_old_pending = false;
     // Parent-side interface pass (level streams, recursive_step): the PARENT's stream computes this level's interface values for
     // the pair of sub-steps 2t, 2t + 1 right after the parent's step t, into set t & 1 of a second pair of side buffers - while this
     // level is still stepping pair t - 1 out of the other set. This level's own stream then carries no interface kernels at all.
@@ -831,6 +836,12 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         }
         L->rho_replay[LUDWIG_PART_ALL].stale = false;
         p.store_rho = store ? 1 : 0;
+        // rho_old in the step (save_old_impl): this launch covers every cell and stores rho
+        if (L->rho_old_pending) {
+            if (part == LUDWIG_PART_ALL && store) p.rho_old_save = L->rho_old;
+            else LW_HIP(hipMemcpyAsync(L->rho_old, L->rho, (size_t)L->sk * 4, hipMemcpyDeviceToDevice, L->stream));
+            L->rho_old_pending = false;
+        }
     }
 
     const bool post = p.f_post != nullptr, wall = p.wall_model != 0;
@@ -845,10 +856,9 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
         // WALL without POST goes through the <POST, WALL> instantiation (no block is flagged for the f_post store, so the null
         // pointer is never used): the register allocator gets <POST = false, WALL = true> down to 96 VGPRs only by spilling
         // 208 B per lane, while the POST variant sits at 88-90 without - same arithmetic, same bits
-        if (general) {
+        if (general) {       // GENERAL without POST needs a 104-byte spill to stay at 96 VGPRs: the POST variant serves it too
             if (wall) LW_LAUNCH_X(true, true, true);
-            else if (post) LW_LAUNCH_X(true, true, false);
-            else LW_LAUNCH_X(true, false, false);
+            else LW_LAUNCH_X(true, true, false);
         } else {
             if (wall) LW_LAUNCH_X(false, true, true);
             else if (post) LW_LAUNCH_X(false, true, false);
@@ -1527,7 +1537,11 @@ int ludwig_step(LudwigLevel *L, const LudwigLevel *parent, int64_t t_sub, float 
     return launch_bouzidi(L, t_sub, flags->q_min_threshold);
 }
 
-int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
+static int save_old_impl(LudwigLevel *L, int64_t t_sub, bool defer_rho);
+
+int ludwig_save_old(LudwigLevel *L, int64_t t_sub) { return save_old_impl(L, t_sub, false); }
+
+static int save_old_impl(LudwigLevel *L, int64_t t_sub, bool defer_rho)
 {
     if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
     if (!L->has_temporal) return LUDWIG_OK;   // reference src/blocks.jl:200
@@ -1548,6 +1562,11 @@ int ludwig_save_old(LudwigLevel *L, int64_t t_sub)
         const int r = ensure_rho(L);
         if (r) return r;
     }
+    if (defer_rho && L->n_owned == L->n_blocks && !L->external_writer && getenv("LUDWIG_RHO_OLD_COPY") == nullptr) {
+        L->rho_old_pending = true;                   // the step that follows saves it cell by cell (launch_stream_collide)
+        return LUDWIG_OK;
+    }
+    L->rho_old_pending = false;
     LW_HIP(hipMemcpyAsync(L->rho_old, L->rho, c * 4, hipMemcpyDeviceToDevice, L->stream));
     return LUDWIG_OK;
 }
@@ -1607,7 +1626,7 @@ static int recursive_step(LudwigLevel *const *levels, int n_levels, int lvl /*1-
         }
     }
     if (has_children && fl->use_temporal_interp && L->has_temporal)
-        if ((rc = ludwig_save_old(L, t_sub))) return rc;
+        if ((rc = save_old_impl(L, t_sub, true))) return rc;      // rho's part rides in the step's launch where it can
     if ((rc = ludwig_step(L, parent, t_sub, u_vel, parent_tau, temporal_weight, fl))) return rc;
     static const bool parent_side = getenv("LUDWIG_CHILD_SIDE_IFACE") == nullptr;      // LUDWIG_CHILD_SIDE_IFACE=1: round 2's placement
     if (concurrent && parent && parent_side && (t_sub & 1) && L->ev_pair_done[0]) {
@@ -1693,6 +1712,7 @@ int ludwig_execute_timestep_batch(LudwigLevel *const *levels, int32_t n_levels, 
             }
         }
     }
+    for (int i = 0; i < n_levels; ++i) levels[i]->rho_old_pending = false;      // (only an aborted batch could have left one)
     int rc = LUDWIG_OK;
     for (int32_t o = 0; o < batch_size && rc == LUDWIG_OK; ++o)
         rc = recursive_step(levels, n_levels, 1, t_start + o, nullptr, 0.5f, 0.0f, u_curr, flags, concurrent);
