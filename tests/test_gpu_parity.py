@@ -460,7 +460,10 @@ def test_interface_pass_ahead_of_the_wait_gives_the_same_bits(gpu, tmp_path, hoi
             "execute_timestep_batch(d, 4, 4, np.float32(0.05), p)\n"
             "np.savez(sys.argv[1], **{f'{n}{i}': x.download(n) for i, x in enumerate(d) for n in ('f', 'f_temp', 'vel', 'vel_temp', 'rho')})\n" % root)
     out = str(tmp_path / "hoist.npz")
-    subprocess.run([sys.executable, "-c", code.replace("\\n", "\n"), out], check=True, env=dict(os.environ, LUDWIG_IFACE_HOIST=hoist))
+    # round 3 computes a level's interface values on its PARENT's stream (no child-side pass left to hoist): LUDWIG_CHILD_SIDE_IFACE and
+    # LUDWIG_RHO_OLD_COPY keep round 2's placement - the path this test is about - alive and compared against the default's oracle-equal bits
+    subprocess.run([sys.executable, "-c", code.replace("\\n", "\n"), out], check=True,
+                   env=dict(os.environ, LUDWIG_IFACE_HOIST=hoist, LUDWIG_CHILD_SIDE_IFACE="1", LUDWIG_RHO_OLD_COPY="1"))
     got = np.load(out)
     grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=3, wall_model=True, tau=0.5003)
     oracle.execute_timestep_batch(grids, 1, 7, np.float32(0.05), params)
