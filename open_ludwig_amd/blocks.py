@@ -177,7 +177,9 @@ class DeviceLevel:
     `copyto!(level.f, host)` in the reference); there is no host shadow copy.
     """
 
-    def __init__(self, host: BlockLevel, device: int = 0):
+    def __init__(self, host: BlockLevel, device: int = 0, upload_state: bool = True):
+        """upload_state=False: skip copying the host level's f / rho / vel arrays (the caller initialises the state on the device,
+        e.g. `init_equilibrium`, src/main.jl:109-134) - on a 55 M-cell level that is 25 GB of zeros over PCIe"""
         lib = _lib.load()
         self._lib = lib
         self.level_id = host.level_id
@@ -228,7 +230,7 @@ class DeviceLevel:
         _lib.check(lib.ludwig_level_create(C.byref(h), device, C.byref(handle)))
         self._h = handle
         # state: the constructor defaults already match; copy whatever the host level holds
-        if self.n_blocks == 0:
+        if self.n_blocks == 0 or not upload_state:
             return
         for name in ("f", "f_temp", "rho", "vel", "vel_temp"):
             self.upload(name, getattr(host, name))
@@ -338,6 +340,6 @@ class DeviceLevel:
         _lib.check(self._lib.ludwig_sync(self.handle))
 
 
-def adapt(host: BlockLevel, device: int = 0) -> DeviceLevel:
+def adapt(host: BlockLevel, device: int = 0, upload_state: bool = True) -> DeviceLevel:
     """grids = [adapt(backend, g) for g in cpu_grids] (src/main.jl:98)"""
-    return DeviceLevel(host, device)
+    return DeviceLevel(host, device, upload_state)

@@ -38,9 +38,9 @@ class HipStepper:
 
     def __init__(self, host_grids, device: int = 0):
         self.host = host_grids
-        self.dev = [adapt(g, device) for g in host_grids]
+        self.dev = [adapt(g, device, upload_state=False) for g in host_grids]
         for d in self.dev:
-            d.init_equilibrium()               # src/main.jl:126-135
+            d.init_equilibrium()               # src/main.jl:126-135 (every state array: nothing of the host's to upload first)
 
     def batch(self, t_start: int, n: int, u_curr, params) -> None:
         execute_timestep_batch(self.dev, t_start, n, u_curr, params)

@@ -450,7 +450,8 @@ def _tri_box_overlap(centers: np.ndarray, half: float, v1: np.ndarray, v2: np.nd
             axis = np.cross(u, f[j])
             use = (axis * axis).sum(axis=2) >= 1e-10
             p1 = (t1 * axis).sum(axis=2); p2 = (t2 * axis).sum(axis=2); p3 = (t3 * axis).sum(axis=2)
-            r = h * np.abs(axis).sum(axis=2)
+            aa = np.abs(axis)
+            r = (h * aa[..., 0] + h * aa[..., 1]) + h * aa[..., 2]          # :28, term by term
             sep = (np.minimum(p1, np.minimum(p2, p3)) > r) | (np.maximum(p1, np.maximum(p2, p3)) < -r)
             ok &= ~(use & sep)
     return ok
@@ -497,17 +498,38 @@ def _tri_box_overlap_pairs(c: np.ndarray, half: float, v1: np.ndarray, v2: np.nd
             axis = np.cross(u, f[j])
             use = (axis * axis).sum(axis=1) >= 1e-10
             p1 = (t1 * axis).sum(axis=1); p2 = (t2 * axis).sum(axis=1); p3 = (t3 * axis).sum(axis=1)
-            r = h * np.abs(axis).sum(axis=1)
+            aa = np.abs(axis)
+            r = (h * aa[:, 0] + h * aa[:, 1]) + h * aa[:, 2]                # :28, term by term
             sep = (np.minimum(p1, np.minimum(p2, p3)) > r) | (np.maximum(p1, np.maximum(p2, p3)) < -r)
             ok &= ~(use & sep)
     return ok
 
 
-def voxelize_blocks(coords, mesh: SolverMesh, dx: float, offset) -> np.ndarray:
+def _native_inputs(coords, mesh: SolverMesh, offset):
+    """(library, int32 [nb,3] block coordinates, Float64 [T,3,3] triangles with the mesh offset added, threads)"""
+    from . import _setup_lib
+    lib = _setup_lib.load()
+    c = np.ascontiguousarray(np.asarray(coords, dtype=np.int32).reshape(-1, 3))
+    tri = None if mesh is None else np.ascontiguousarray(mesh.triangles + np.asarray(offset), dtype=np.float64)
+    return lib, c, tri, _setup_lib.n_threads()
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data
+
+
+def voxelize_blocks(coords, mesh: SolverMesh, dx: float, offset, method: str = "native") -> np.ndarray:
     """voxelize_blocks! (src/domain_generation.jl:74-112). The reference tests every cell of a block against the
     triangles binned to that block (margin 2 dx); a triangle can only touch a cell's 0.75 dx half-box if the cell centre
-    is within 0.75075 dx of the triangle's bounding box, so testing exactly those pairs gives the same voxels."""
+    is within 0.75075 dx of the triangle's bounding box, so testing exactly those pairs gives the same voxels.
+    method "native": libludwig_setup.so, block by block like the reference; "numpy": the restatement below (the checker)."""
     n = len(coords)
+    if method == "native":
+        from . import _setup_lib
+        lib, c, tri, nt = _native_inputs(coords, mesh, offset)
+        obs = np.zeros((BS, BS, BS, n), dtype=np.uint8, order="F")
+        _setup_lib.check(lib.lws_voxelize(_ptr(tri), tri.shape[0], float(dx), _ptr(c), n, _ptr(obs), nt), "lws_voxelize")
+        return obs.view(np.bool_)
     d = _Dense(coords)
     tri = mesh.triangles + np.asarray(offset)
     cell, ti, centre = _candidate_pairs(tri.min(axis=1), tri.max(axis=1), 0.75 * dx * 1.001, dx, d)
@@ -517,9 +539,14 @@ def voxelize_blocks(coords, mesh: SolverMesh, dx: float, offset) -> np.ndarray:
     return d.to_blocks(dense, n)
 
 
-def perform_flood_fill(obstacle: np.ndarray, coords) -> int:
+def perform_flood_fill(obstacle: np.ndarray, coords, method: str = "native") -> int:
     """6-connected fill of everything not reachable from the fluid cells of the min-x blocks (src/domain_generation.jl:114-203).
     Returns the number of interior voxels turned solid (the count the reference prints)."""
+    if method == "native":
+        from . import _setup_lib
+        lib, c, _, _ = _native_inputs(coords, None, None)
+        assert obstacle.flags.f_contiguous and obstacle.dtype == np.bool_
+        return _setup_lib.check(lib.lws_flood_fill(_ptr(c), len(coords), _ptr(obstacle)), "lws_flood_fill")
     from scipy import ndimage
     d = _Dense(coords)
     obs = d.to_dense(obstacle)
@@ -552,22 +579,38 @@ def apply_sponge(coords, params: DomainParameters, lvl_scale: int, cfg: CaseConf
     inlet_t = Lx * 0.02
     y_t, z_t = Ly * st * 0.5, Lz * st * 0.5
     outlet_start, y_top, z_back = Lx - outlet_t, Ly - y_t, Lz - z_t
-    px, py, pz = _cell_centers(coords, dx)
-    val = np.zeros(px.shape)
-    val = np.where(px > outlet_start, np.maximum(val, _profile(outlet_t - (px - outlet_start), outlet_t) * 1.0), val)
-    val = np.where(px < inlet_t, np.maximum(val, _profile(px, inlet_t) * 0.05), val)
+    # every term depends on ONE coordinate and the result is their maximum: evaluate the profiles on the [8, nb] coordinate arrays
+    # of each axis and combine by broadcasting (same expressions on the same Float64 inputs as the cell-by-cell form)
+    c = np.asarray(coords, dtype=np.float64)
+    l = np.arange(1, BS + 1, dtype=np.float64)
+    px, py, pz = (((c[:, a][None, :] - 1) * BS + l[:, None] - 0.5) * dx for a in range(3))
+    vx = np.zeros(px.shape)
+    vx = np.where(px > outlet_start, np.maximum(vx, _profile(outlet_t - (px - outlet_start), outlet_t) * 1.0), vx)
+    vx = np.where(px < inlet_t, np.maximum(vx, _profile(px, inlet_t) * 0.05), vx)
+    vy = np.zeros(py.shape)
     if not cfg.symmetric_analysis:
-        val = np.where(py < y_t, np.maximum(val, _profile(py, y_t) * 0.1), val)
-    val = np.where(py > y_top, np.maximum(val, _profile(y_t - (py - y_top), y_t) * 0.1), val)
-    val = np.where(pz < z_t, np.maximum(val, _profile(pz, z_t) * 0.1), val)
-    val = np.where(pz > z_back, np.maximum(val, _profile(z_t - (pz - z_back), z_t) * 0.1), val)
-    return np.asfortranarray(val.astype(np.float32))
+        vy = np.where(py < y_t, np.maximum(vy, _profile(py, y_t) * 0.1), vy)
+    vy = np.where(py > y_top, np.maximum(vy, _profile(y_t - (py - y_top), y_t) * 0.1), vy)
+    vz = np.zeros(pz.shape)
+    vz = np.where(pz < z_t, np.maximum(vz, _profile(pz, z_t) * 0.1), vz)
+    vz = np.where(pz > z_back, np.maximum(vz, _profile(z_t - (pz - z_back), z_t) * 0.1), vz)
+    vx, vy, vz = (v.astype(np.float32) for v in (vx, vy, vz))          # rounding is monotone: max then round = round then max
+    # built as C-ordered [nb, z, y, x] (memory order of the Fortran [x, y, z, nb] array the level holds), returned as that view
+    val = np.maximum(np.maximum(vx.T[:, None, None, :], vy.T[:, None, :, None]), vz.T[:, :, None, None])
+    return val.transpose(3, 2, 1, 0)
 
 
 # ----------------------------------------------------------------------------------------------------------------
 # wall distance, src/domain_generation.jl:371-434 (values are metres used as lattice units downstream: Appendix A.6)
 # ----------------------------------------------------------------------------------------------------------------
-def compute_wall_distances(coords, obstacle: np.ndarray, dx: float) -> np.ndarray:
+def compute_wall_distances(coords, obstacle: np.ndarray, dx: float, method: str = "native") -> np.ndarray:
+    if method == "native":
+        from . import _setup_lib
+        lib, c, _, nt = _native_inputs(coords, None, None)
+        assert obstacle.flags.f_contiguous and obstacle.dtype == np.bool_
+        wall = np.full(obstacle.shape, np.float32(100.0), dtype=np.float32, order="F")
+        _setup_lib.check(lib.lws_wall_distance(_ptr(c), len(coords), _ptr(obstacle), float(dx), _ptr(wall), nt), "lws_wall_distance")
+        return wall
     d = _Dense(coords)
     obs = d.to_dense(obstacle)
     best = np.full(d.shape, np.float32(100.0), dtype=np.float32)
@@ -591,15 +634,34 @@ def compute_wall_distances(coords, obstacle: np.ndarray, dx: float) -> np.ndarra
 # ----------------------------------------------------------------------------------------------------------------
 # Bouzidi q-map, src/bouzidi_setup.jl:64-167 + src/bouzidi_math.jl:9-102
 # ----------------------------------------------------------------------------------------------------------------
-def compute_bouzidi_qmap_sparse(coords, mesh: SolverMesh, dx: float, offset, shell: Optional[np.ndarray] = None):
+def _boundary_cell_lists(mark: np.ndarray):
+    """sorted boundary-cell lists (block, then z, y, x) from a bool [8,8,8,nb] (F order) marker"""
+    flat = np.flatnonzero(mark.reshape(-1, order="F"))
+    b, cell = flat // 512, flat % 512
+    return ((b + 1).astype(np.int32), (cell % 8 + 1).astype(np.int8), ((cell // 8) % 8 + 1).astype(np.int8),
+            (cell // 64 + 1).astype(np.int8), int(flat.shape[0]))
+
+
+def compute_bouzidi_qmap_sparse(coords, mesh: SolverMesh, dx: float, offset, shell: Optional[np.ndarray] = None, method: str = "native"):
     """Returns (q_map Float16 [8,8,8,nb,27], cell_block, cell_x, cell_y, cell_z (1-based), n_boundary_cells).
 
     The reference casts, from every cell of every block that has triangles binned to it (margin 2.5 dx), 26 rays against
     all binned triangles and keeps q = t_min / (dx |c|) if 0 < q <= 1. A link is at most sqrt(3) dx long, so only
     triangles whose bounding box is within sqrt(3) dx of the cell centre can give q <= 1, and a farther triangle can
     never undercut a nearer hit: evaluating exactly those (cell, triangle) pairs gives the same q-map. The list order is
-    thread-dependent in the reference and irrelevant (Appendix A.11); here it is sorted."""
+    thread-dependent in the reference and irrelevant (Appendix A.11); here it is sorted.
+    method "native": libludwig_setup.so (a thread per block, as the reference); "numpy": the restatement below (the checker)."""
     n = len(coords)
+    if method == "native":
+        from . import _setup_lib
+        lib, c, tri, nt = _native_inputs(coords, mesh, offset)
+        q_map = np.zeros((BS, BS, BS, n, 27), dtype=np.float16, order="F")
+        mark = np.zeros((BS, BS, BS, n), dtype=np.uint8, order="F")
+        nbc = _setup_lib.check(lib.lws_bouzidi_qmap(_ptr(tri), tri.shape[0], float(dx), _ptr(c), n, _ptr(q_map), _ptr(mark), nt),
+                               "lws_bouzidi_qmap")
+        cb, cx, cy, cz, cnt = _boundary_cell_lists(mark)
+        assert cnt == nbc
+        return q_map, cb, cx, cy, cz, nbc
     d = _Dense(coords)
     tri = mesh.triangles + np.asarray(offset)
     cell, ti, o = _candidate_pairs(tri.min(axis=1), tri.max(axis=1), math.sqrt(3.0) * dx * 1.0001, dx, d)
@@ -662,8 +724,13 @@ class SetupReport:
     bouzidi_cells: List[int] = field(default_factory=list)
 
 
-def setup_multilevel_domain(cfg: CaseConfig, stl_path: Optional[str] = None):
-    """setup_multilevel_domain(stl_path) (src/domain.jl:268-280) -> (grids, mesh, params, report)."""
+def setup_multilevel_domain(cfg: CaseConfig, stl_path: Optional[str] = None, method: Optional[str] = None):
+    """setup_multilevel_domain(stl_path) (src/domain.jl:268-280) -> (grids, mesh, params, report).
+    method: "native" (default; libludwig_setup.so, threads over blocks) or "numpy" (the restatement the native code is checked
+    against; env LUDWIG_SETUP_METHOD). There is no silent fall-back from one to the other."""
+    method = method or os.environ.get("LUDWIG_SETUP_METHOD", "native")
+    if method not in ("native", "numpy"):
+        raise ValueError(f"setup method {method!r}: native or numpy")
     stl = stl_path or os.path.join(cfg.case_dir, cfg.stl_file)
     mesh = load_mesh(stl, scale=cfg.stl_scale)
     params = compute_domain_from_mesh(mesh.min_bounds, mesh.max_bounds, cfg)
@@ -711,20 +778,20 @@ def setup_multilevel_domain(cfg: CaseConfig, stl_path: Optional[str] = None):
         rep.halo_blocks_added.append(len(active) - n_before if lvl > 1 else None)
         coords = sorted(active)
         table = build_neighbor_table(coords, *bmax)
-        obstacle = voxelize_blocks(coords, mesh, dx, off)
+        obstacle = voxelize_blocks(coords, mesh, dx, off, method=method)
         shell = obstacle.copy()
-        rep.flood_fill_filled.append(perform_flood_fill(obstacle, coords))
+        rep.flood_fill_filled.append(perform_flood_fill(obstacle, coords, method=method))
         sponge = apply_sponge(coords, params, scale, cfg)
         rep.sponge_fraction.append(float((sponge > 0).mean()))
         rep.sponge_max.append(float(sponge.max()))
         wall = None
         if cfg.wall_model_enabled:
-            wall = compute_wall_distances(coords, obstacle, dx)
+            wall = compute_wall_distances(coords, obstacle, dx, method=method)
             rep.near_wall_cells.append(int((wall != np.float32(100.0)).sum()))
         use_bouzidi = cfg.boundary_method == "bouzidi" and lvl > params.num_levels - cfg.bouzidi_levels
         kw = {}
         if use_bouzidi:
-            q, cb, cx, cy, cz, nbc = compute_bouzidi_qmap_sparse(coords, mesh, dx, off, shell)
+            q, cb, cx, cy, cz, nbc = compute_bouzidi_qmap_sparse(coords, mesh, dx, off, shell, method=method)
             kw = dict(bouzidi_q_map=q, bouzidi_cell_block=cb, bouzidi_cell_x=cx, bouzidi_cell_y=cy, bouzidi_cell_z=cz, n_boundary_cells=nbc)
             rep.bouzidi_cells.append(nbc)
         level = BlockLevel(lvl, coords, table, float(np.float32(dx)), np.float32(1.0) / np.float32(scale), params.tau_levels[lvl - 1],
