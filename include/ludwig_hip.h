@@ -89,9 +89,12 @@ typedef struct LudwigLevelHost {
     const int32_t  *bouzidi_cell_block;           /* [n_boundary_cells] 1-based                     */
     const int8_t   *bouzidi_cell_x, *bouzidi_cell_y, *bouzidi_cell_z;   /* 1-based local coords     */
     const uint8_t  *comm_boundary; /* optional [n_blocks]: 1 = owned block adjacent to a ghost block */
-    int32_t store_post_collision_everywhere;      /* 0: f_post_collision is written only where it has a reader - blocks that
-                                      hold a listed Bouzidi cell or a cell adjacent to one (the reference writes it for every
-                                      cell, src/physics_kernels.jl:350-352, and reads it only there, src/bouzidi_kernel.jl:44-77).
+    int32_t store_post_collision_everywhere;      /* 0: f_post_collision is written only where it has a reader (the reference writes
+                                      it for every cell, src/physics_kernels.jl:350-352, and reads it only in the Bouzidi kernel,
+                                      src/bouzidi_kernel.jl:44-77): the x-rows of 8 cells that hold a listed Bouzidi cell with a link
+                                      q > 0 or the cell one step behind such a link; whole blocks that hold or touch a listed cell
+                                      when the step's q_min_threshold is negative (every direction is a link then) or with
+                                      LUDWIG_POST_ROWS=0. The rest of the array keeps what it held (zeros after create).
                                       1: every block, as the reference (multi-GPU: a peer's cells read this rank's blocks)  */
 } LudwigLevelHost;
 

@@ -100,7 +100,7 @@ class DistributedStepper:
 
     def _start(self, params) -> None:
         self.runner = self.partition.MultiLevelRunner(self.host, self.owners, params, self.rank, self.world, self.device, self.stage,
-                                                      overlap=self.overlap, transport=self.transport)
+                                                      overlap=self.overlap, transport=self.transport, upload_state=False)
         for lv in self.runner.levels:
             if lv is not None:
                 lv.init_equilibrium()          # src/main.jl:126-135 (ghost blocks included: same rest state everywhere)

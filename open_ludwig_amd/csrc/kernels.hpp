@@ -34,6 +34,8 @@ struct SCParams {
     const float *f_in;
     float *f_out;
     float *f_post;            // nullptr unless store_post_collision
+    const uint32_t *post_rows; // [n_blocks][2]: bit z*8+y of a block's 64 = the x-row (y, z) holds a cell f_post_collision is read at;
+                              // nullptr = every row of a block flagged FLAG_STORE_POST
     const float *vel_in;
     float *vel_out;
     float *rho;
@@ -320,7 +322,19 @@ __device__ __forceinline__ void finish_cell(const SCParams &p, const int flags, 
     // the reference stores f_post_collision for every cell of a Bouzidi level (src/physics_kernels.jl:350-352); its only
     // reader is the Bouzidi kernel, at boundary cells and their link neighbours, so blocks that neither hold nor touch a
     // boundary cell skip the dead store (wave-uniform flag; 108 of 357 B per cell update)
-    const bool store_post = (flags & FLAG_STORE_POST) != 0;
+    // Round 3: inside such a block only the x-rows (8 cells = one 32-B sector per population) that hold a Bouzidi cell or the
+    // cell one step behind a link are stored (`post_rows`, one bit per row; the word is wave-uniform: block and plane are).
+    bool store_post = false;
+    if constexpr (POST) {
+        if (flags & FLAG_STORE_POST) {
+            store_post = true;
+            if (p.post_rows) {
+                const int zu = __builtin_amdgcn_readfirstlane((int)(own.cell4 >> 8));
+                const uint32_t w = p.post_rows[(size_t)own.b * 2 + (zu >> 2)];
+                store_post = ((w >> ((zu & 3) * 8 + ((own.cell4 >> 5) & 7))) & 1u) != 0;
+            }
+        }
+    }
     // ---- obstacle cell: full-way bounce-back of the pulled set, reference :154-166 ----
     bool is_obs = false;
     if (flags & FLAG_HAS_OBSTACLE) is_obs = p.obstacle[(size_t)own.b * CELLS + (own.cell4 >> 2)] != 0;

@@ -77,6 +77,8 @@ struct LudwigLevel {
     int n_bc = 0;
     int4 *bouzidi_links = nullptr;      // every listed link with q > 0 (the q map is static): kernels.hpp BouzidiParams::links
     int n_bouzidi_links = 0;
+    uint32_t *post_rows = nullptr;      // [n_blocks][2] bits: the x-rows f_post_collision is read at by the links with q > 0 (SCParams::post_rows)
+    bool post_rows_used = false;        // the last stream-collide stored f_post_collision by rows (valid for q_min >= 0 only)
     _Float16 *q_map = nullptr;
     int32_t *cell_block = nullptr;
     int8_t *cell_x = nullptr, *cell_y = nullptr, *cell_z = nullptr;
@@ -795,6 +797,10 @@ int launch_stream_collide(LudwigLevel *L, const LudwigLevel *parent, int64_t t_s
     // reference src/physics_v2.jl:77: store_post_collision = bouzidi_enabled && n_boundary_cells > 0; a rank that owns no
     // Bouzidi cell of a Bouzidi level still stores it when asked to (n_boundary_cells < 0): a peer's cells read its face layer
     p.f_post = L->has_post ? L->f_post : nullptr;
+    // rows: the links with q > 0 are the only readers as long as q_min >= 0 (a negative threshold makes every direction of a listed
+    // cell a link, src/bouzidi_kernel.jl:44: whole blocks then)
+    p.post_rows = (p.f_post && fl->q_min_threshold >= 0.0f) ? L->post_rows : nullptr;
+    if (p.f_post) L->post_rows_used = p.post_rows != nullptr;
     p.obstacle = L->obstacle;
     p.sponge = L->sponge;
     p.wall_dist = L->wall_dist;
@@ -937,6 +943,9 @@ int launch_bouzidi(LudwigLevel *L, int64_t t_sub, float q_min)
 {
     if (!L) return fail(LUDWIG_ERR_INVALID, "null level");
     if (!(L->bouzidi_enabled && L->n_bc > 0)) return LUDWIG_OK;   // reference src/bouzidi_kernel.jl:107-109
+    if (q_min < 0.0f && L->post_rows_used)
+        return fail(LUDWIG_ERR_STATE, "q_min_threshold < 0 makes every direction a link: the stream-collide call must be given the same "
+                                      "threshold (it stored f_post_collision for the links with q > 0 only)");
     ++L->version;
     LW_HIP(hipSetDevice(L->device));
     const int out = (t_sub % 2 == 0) ? 1 : 0;
@@ -1040,6 +1049,7 @@ void ludwig_level_destroy(LudwigLevel *L)
     if (L->ev_stepped) (void)hipEventDestroy(L->ev_stepped);
     if (L->ev_consumed) (void)hipEventDestroy(L->ev_consumed);
     if (L->bouzidi_links) (void)hipFree(L->bouzidi_links);
+    if (L->post_rows) (void)hipFree(L->post_rows);
     if (L->f_iface2) (void)hipFree(L->f_iface2);
     {
         void *more[] = {L->f_iface_b, L->f_iface2_b, L->mac_b, L->mac2_b};
@@ -1244,6 +1254,7 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
         else if ((r = fill(L, L->wall_dist, L->sk, 100.0f))) return r;
         // block_pointer stays on the host: its only use is the static corner lookup of a child's interface links
         if (h->block_pointer && nptr > 0) L->h_block_pointer.assign(h->block_pointer, h->block_pointer + nptr);
+        std::vector<int4> bl;               // the links with q > 0: (own cell, k, q bits, cell behind or -1)
         if (L->bouzidi_enabled) {
             {   // host: population-major (already in the internal block order here), device: block-major
                 const int r = copy_field(L, L->q_map, const_cast<uint16_t *>(h->bouzidi_q_map), Q, 2, true);
@@ -1261,7 +1272,6 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             LW_HIP(hipMemcpy(L->cell_x, cx.data(), cx.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_y, cy.data(), cy.size(), hipMemcpyHostToDevice));
             LW_HIP(hipMemcpy(L->cell_z, cz.data(), cz.size(), hipMemcpyHostToDevice));
-            std::vector<int4> bl;
             const _Float16 *qh = reinterpret_cast<const _Float16 *>(h->bouzidi_q_map);
             for (int i = 0; i < L->n_bc; ++i) {
                 const int own = cb[i] * CELLS + cx[i] + 8 * cy[i] + 64 * cz[i];
@@ -1280,6 +1290,10 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
                     bl.push_back(make_int4(own, k, qbits, behind));
                 }
             }
+            // population-major, cells in memory order inside a population: the lanes of a wave then work on ONE population array at
+            // cells that are mostly neighbours along x - their f_post loads and f_out stores share 32-B sectors instead of touching 64
+            // different 2-KiB population slices of a few cells (every link writes its own (cell, opp k): the order is free)
+            std::sort(bl.begin(), bl.end(), [](const int4 &a, const int4 &c) { return a.y != c.y ? a.y < c.y : a.x < c.x; });
             L->n_bouzidi_links = (int)bl.size();
             if (!bl.empty()) {
                 LW_HIP(hipMalloc((void **)&L->bouzidi_links, bl.size() * sizeof(int4)));
@@ -1302,6 +1316,16 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
                             const int nb2 = row[DIR(ox, oy, oz)];
                             if (nb2 >= 0) L->h_meta[(size_t)nb2 * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
                         }
+            }
+            // inside those blocks: the x-rows a link with q > 0 reads - its own cell and the cell one step behind
+            // (LUDWIG_POST_ROWS=0: whole blocks, round 2's granularity)
+            const char *pr = getenv("LUDWIG_POST_ROWS");
+            if (!everywhere && !bl.empty() && !(pr && pr[0] == '0')) {
+                std::vector<uint32_t> rows((size_t)L->n_blocks * 2, 0u);
+                auto mark = [&](int cell) { const int row = (cell & (CELLS - 1)) >> 3; rows[(size_t)(cell / CELLS) * 2 + (row >> 5)] |= 1u << (row & 31); };
+                for (const int4 &l : bl) { mark(l.x); if (l.w >= 0) mark(l.w); }
+                LW_HIP(hipMalloc((void **)&L->post_rows, rows.size() * 4));
+                LW_HIP(hipMemcpy(L->post_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
             }
         }
         LW_HIP(hipStreamSynchronize(L->stream));

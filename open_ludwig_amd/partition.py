@@ -92,22 +92,40 @@ def build_local_level(level_id: int, coords: Sequence[Tuple[int, int, int]], nei
     return LocalView(rank, lvl, l2g, {int(g): i for i, g in enumerate(l2g)}, len(owned), owner[ghosts])
 
 
-def slice_level_fields(view: LocalView, source: BlockLevel) -> None:
+def _take_blocks(a: np.ndarray, g: np.ndarray) -> np.ndarray:
+    """a[:, :, :, g] (and a[:, :, :, g, :]) of a Fortran-ordered level array as whole 512-cell chunks: the transposed view is
+    C-contiguous [K][block][z][y][x], so the gather moves 2-KiB pieces instead of single elements"""
+    if not a.flags.f_contiguous:
+        return np.asfortranarray(a[:, :, :, g])
+    n = a.shape[3]
+    if a.ndim == 4:
+        return np.take(a.T.reshape(n, 512), g, axis=0).reshape(len(g), 8, 8, 8).T
+    k = a.shape[4]
+    return np.take(a.T.reshape(k, n, 512), g, axis=1).reshape(k, len(g), 8, 8, 8).T
+
+
+def slice_level_fields(view: LocalView, source: BlockLevel, state: bool = True) -> None:
     """Fill a local level (owned + ghost blocks) from a populated GLOBAL host level: state, geometry, sponge, wall
-    distance and the Bouzidi data of the owned blocks (cell list re-indexed to local block ids)."""
+    distance and the Bouzidi data of the owned blocks (cell list re-indexed to local block ids).
+    state=False: geometry only - for callers that initialise the state on the device afterwards (DistributedStepper: init_eq!)."""
     lvl, g = view.level, view.local_to_global
-    for name in ("rho", "vel", "vel_temp", "f", "f_temp", "obstacle", "sponge", "wall_dist"):
-        getattr(lvl, name)[...] = getattr(source, name)[:, :, :, g]
-    if lvl.f_old.size > 27 and source.f_old.size > 27:
+    def take(name):
+        a = _take_blocks(getattr(source, name), g)          # a new Fortran-ordered array of the local level's shape: it replaces the
+        assert a.shape == getattr(lvl, name).shape and a.dtype == getattr(lvl, name).dtype, name       # default one (no second copy)
+        setattr(lvl, name, a)
+
+    for name in (("rho", "vel", "vel_temp", "f", "f_temp") if state else ()) + ("obstacle", "sponge", "wall_dist"):
+        take(name)
+    if state and lvl.f_old.size > 27 and source.f_old.size > 27:
         for name in ("f_old", "rho_old", "vel_old"):
-            getattr(lvl, name)[...] = getattr(source, name)[:, :, :, g]
+            take(name)
     if source.bouzidi_enabled:
         g2l = np.full(source.n_blocks, -1, dtype=np.int64)
         g2l[g[: view.n_owned]] = np.arange(view.n_owned)
         lb = g2l[source.bouzidi_cell_block.astype(np.int64) - 1]
         keep = lb >= 0
         B = BLOCK_SIZE
-        lvl.bouzidi_q_map = np.asfortranarray(source.bouzidi_q_map[:, :, :, g])
+        lvl.bouzidi_q_map = _take_blocks(source.bouzidi_q_map, g)
         lvl.bouzidi_cell_block = (lb[keep] + 1).astype(np.int32)
         lvl.bouzidi_cell_x = source.bouzidi_cell_x[keep].copy()
         lvl.bouzidi_cell_y = source.bouzidi_cell_y[keep].copy()
@@ -115,8 +133,10 @@ def slice_level_fields(view: LocalView, source: BlockLevel) -> None:
         lvl.n_boundary_cells = int(keep.sum())
         lvl.bouzidi_enabled = lvl.n_boundary_cells > 0
         # every rank of a Bouzidi level stores f_post_collision (its ghosts may be asked for it)
-        lvl.f_post_collision = np.zeros((B, B, B, lvl.n_blocks, 27), dtype=np.float32, order="F")
-        lvl.f_post_collision[...] = source.f_post_collision[:, :, :, g] if source.f_post_collision.size > 27 else 0.0
+        if state and source.f_post_collision.size > 27:
+            lvl.f_post_collision = _take_blocks(source.f_post_collision, g)
+        else:
+            lvl.f_post_collision = np.zeros((B, B, B, lvl.n_blocks, 27), dtype=np.float32, order="F")
         # keep the store of f_post_collision alive in every block of this rank: a peer's Bouzidi cells may read our face layer
         lvl.force_post_collision = True
 
@@ -906,7 +926,9 @@ class MultiLevelRunner:
 
     def __init__(self, grids: Sequence[BlockLevel], owners, params, rank: int, world: int, device: int,
                  stage_through_host: bool = False, overlap: bool = True, transport: Optional[str] = None, comm=None,
-                 wire_ranks: Optional[List[Dict[int, int]]] = None, requests_to_me: Optional[Callable] = None):
+                 wire_ranks: Optional[List[Dict[int, int]]] = None, requests_to_me: Optional[Callable] = None, upload_state: bool = True):
+        """upload_state=False: the host levels' f / rho / vel arrays are neither sliced nor uploaded - the caller initialises the state
+        on the device right away (DistributedStepper: init_eq!); on the shipped Wing_5_deg that is 25 GB of zeros per rank otherwise"""
         import ctypes as C
         import torch
         from . import _lib
@@ -928,7 +950,7 @@ class MultiLevelRunner:
                 extra = required_parent_blocks(grids[i + 1], child_owned, g)
             v = build_local_level(g.level_id, g.active_block_coords, g.neighbor_table, owners[i], rank, float(g.tau),
                                   temporal=g.f_old.size > 27, extra_ghosts=extra)
-            slice_level_fields(v, g)
+            slice_level_fields(v, g, state=upload_state)
             views[i] = v
         self.views = views
         torch.cuda.set_device(device)
@@ -963,7 +985,7 @@ class MultiLevelRunner:
                             blk = (np.asarray(off, dtype=np.int64) % sk) // 512
                             v.level.comm_boundary[blk[blk < v.n_owned]] = 1
         # no local copy at all of a level: None (skipped); only ghost copies (parent data for finer blocks): kept, never stepped
-        self.levels = [adapt(v.level, device) if v.level.n_blocks > 0 else None for v in self.views]
+        self.levels = [adapt(v.level, device, upload_state) if v.level.n_blocks > 0 else None for v in self.views]
         self.plans = plans
         self.overlap = overlap
         self.transport = transport or ("torch" if stage_through_host else os.environ.get("LUDWIG_HALO_TRANSPORT", "native"))

@@ -43,6 +43,30 @@ def post_collision_blocks(g):
     return m
 
 
+def post_collision_rows(g):
+    """bool [8,8,8,nb]: the x-rows (8 cells) that hold a cell f_post_collision is READ at by a link with q > 0 - the Bouzidi cell itself
+    and the cell one step behind it along the link (src/bouzidi_kernel.jl:44-77). The library stores f_post_collision there and
+    nowhere else (include/ludwig_hip.h: store_post_collision_everywhere)."""
+    m = np.zeros((8, 8, 8, g.n_blocks), dtype=bool)
+    cb = g.bouzidi_cell_block.astype(np.int64) - 1
+    x, y, z = (a.astype(np.int64) - 1 for a in (g.bouzidi_cell_x, g.bouzidi_cell_y, g.bouzidi_cell_z))
+    nt = np.asarray(g.neighbor_table)
+    for k in range(27):
+        q = g.bouzidi_q_map[x, y, z, cb, k].astype(np.float32)
+        sel = q > 0
+        if not sel.any():
+            continue
+        c = (k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1)
+        b0, p0 = cb[sel], [x[sel], y[sel], z[sel]]
+        m[:, p0[1], p0[2], b0] = True
+        n = [p - d for p, d in zip(p0, c)]                     # x + c_opp(k)
+        o = [np.where(v < 0, -1, np.where(v > 7, 1, 0)) for v in n]
+        nb = np.where((o[0] == 0) & (o[1] == 0) & (o[2] == 0), b0 + 1, nt[b0, (o[0] + 1) + 3 * (o[1] + 1) + 9 * (o[2] + 1)])
+        ok = nb > 0
+        m[:, (n[1] % 8)[ok], (n[2] % 8)[ok], nb[ok] - 1] = True
+    return m
+
+
 def compare(grids, dev, steps, exact=True):
     for i, (g, d) in enumerate(zip(grids, dev)):
         fn, vn = oracle.newest_buffers(i, steps)
@@ -55,10 +79,10 @@ def compare(grids, dev, steps, exact=True):
             a, b = d.download(name), getattr(g, name)
             assert np.isfinite(b).all(), f"oracle produced non-finite {name}"
             if name == "f_post_collision" and not getattr(g, "force_post_collision", False):
-                # written only where it has a reader: blocks holding a Bouzidi cell and their neighbours (include/ludwig_hip.h)
-                m = post_collision_blocks(g)
+                # written only where it has a reader: the x-rows of the Bouzidi cells and of the cells behind their links (include/ludwig_hip.h)
+                m = post_collision_rows(g)
                 assert 0 < m.sum()
-                a, b = a[:, :, :, m], b[:, :, :, m]
+                a, b = a[m], b[m]
             if exact:
                 bad = np.argwhere(a != b)
                 assert bad.size == 0, (f"level {i + 1} {name}: {bad.shape[0]} elements differ, first at {bad[0]}, "
@@ -220,28 +244,54 @@ def test_saved_old_state_survives_steps_without_a_new_save(gpu):
     d.close()
 
 
-def test_post_collision_store_modes(gpu):
-    """Default: f_post_collision is written only in blocks that hold or touch a Bouzidi cell (elsewhere the store is dead:
-    src/bouzidi_kernel.jl:44-77 is its only reader). store_post_collision_everywhere restores the reference's full array.
-    Either way the populations are the same."""
+def test_post_collision_store_modes(gpu, monkeypatch):
+    """Default: f_post_collision is written only in the x-rows its only reader, src/bouzidi_kernel.jl:44-77, looks at (elsewhere the
+    store is dead); LUDWIG_POST_ROWS=0: in whole blocks that hold or touch a Bouzidi cell (round 2); store_post_collision_everywhere
+    restores the reference's full array. Either way the populations are the same."""
     results = []
-    for everywhere in (False, True):
+    for mode in ("rows", "blocks", "everywhere"):
+        if mode == "blocks":
+            monkeypatch.setenv("LUDWIG_POST_ROWS", "0")
+        else:
+            monkeypatch.delenv("LUDWIG_POST_ROWS", raising=False)
         grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=2, wall_model=False, temporal=True)
         for g in grids:
-            g.force_post_collision = everywhere
+            g.force_post_collision = mode == "everywhere"
         dev = run_both(grids, params, 3, 0.05)
         fin, d = grids[-1], dev[-1]
-        m = post_collision_blocks(fin)
-        assert 0 < m.sum() < fin.n_blocks
+        mb, mr = post_collision_blocks(fin), post_collision_rows(fin)
+        assert 0 < mb.sum() < fin.n_blocks and 0 < mr.sum() < mr[:, :, :, mb].size and not mr[:, :, :, ~mb].any()
         fp = d.download("f_post_collision")
-        assert np.array_equal(fp[:, :, :, m], fin.f_post_collision[:, :, :, m])
-        if everywhere:
+        assert np.array_equal(fp[mr], fin.f_post_collision[mr])
+        if mode == "everywhere":
             assert np.array_equal(fp, fin.f_post_collision)
+        elif mode == "blocks":
+            assert np.array_equal(fp[:, :, :, mb], fin.f_post_collision[:, :, :, mb])
+            assert not fp[:, :, :, ~mb].any(), "blocks without a reader keep their initial zeros"
         else:
-            assert not fp[:, :, :, ~m].any(), "blocks without a reader keep their initial zeros"
+            assert not fp[~mr].any(), "rows without a reader keep their initial zeros"
         results.append(d.download("f"))
         compare(grids, dev, 3)
-    assert np.array_equal(results[0], results[1])
+    assert np.array_equal(results[0], results[1]) and np.array_equal(results[0], results[2])
+
+
+def test_negative_q_min_threshold_makes_every_direction_a_link(gpu):
+    """`q > q_min && q <= 1` (src/bouzidi_kernel.jl:44) with a NEGATIVE threshold also takes the directions whose q is 0: every listed
+    cell then reads f_post_collision at all its neighbours. The row-granular store only covers links with q > 0, so the library
+    stores whole blocks for such a step (and refuses a correction whose threshold contradicts the store). Same bits as the oracle."""
+    import dataclasses
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=2, wall_model=False, temporal=True)
+    params = dataclasses.replace(params, q_min_threshold=-1.0)
+    dev = run_both(grids, params, 3, 0.05)
+    compare(grids, dev, 3)
+    # stream-collide told q_min >= 0, correction asked with q_min < 0: an error, not wrong numbers
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=2, wall_model=False, temporal=True)
+    dev = run_both(grids, params, 1, 0.05)
+    from open_ludwig_amd import _lib
+    lib = _lib.load()
+    assert lib.ludwig_bouzidi_correction(dev[-1].handle, 1, -1.0) == -5          # LUDWIG_ERR_STATE
+    for d in dev:
+        d.close()
 
 
 def test_interface_values_computed_ahead_are_dropped_when_the_parent_changes(gpu, monkeypatch):

@@ -16,7 +16,10 @@ OVERRIDES = {"basic": {"surface_resolution": 200, "num_levels": 3}}
 
 
 def run(steps=None, diag_freq=100, log=None, shipped=False):
-    cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"), None if shipped else OVERRIDES)
+    over = None if shipped else OVERRIDES
+    if os.environ.get("WING_OVERRIDES"):          # experiments only, e.g. '{"advanced": {"boundary": {"method": "bounce_back"}}}'
+        over = json.loads(os.environ["WING_OVERRIDES"])
+    cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"), over)
     assert (cfg.steps, cfg.ramp_steps) == (10000, 2000), "the shipped run length"
     cfg.diag_freq = diag_freq
     t0 = time.time()
@@ -25,7 +28,14 @@ def run(steps=None, diag_freq=100, log=None, shipped=False):
     if log:
         log(f"set-up {t_setup:.1f} s: blocks {setup[3].level_blocks}, Bouzidi cells {setup[3].bouzidi_cells}, tau {[float(g.tau) for g in setup[0]]}")
     t0 = time.time()
-    rows, rep, params = case.run_case(cfg, case.HipStepper, steps=steps, setup=setup, log=log)
+    stamps = []
+
+    def stamped(line):
+        stamps.append(time.time())
+        if log:
+            log(line)
+
+    rows, rep, params = case.run_case(cfg, case.HipStepper, steps=steps, setup=setup, log=stamped)
     t_run = time.time() - t0
     total = steps or cfg.steps
     work = sum(g.n_blocks * 512 * 2 ** i for i, g in enumerate(setup[0]))
@@ -38,6 +48,9 @@ def run(steps=None, diag_freq=100, log=None, shipped=False):
         "level_blocks": rep.level_blocks, "bouzidi_cells": rep.bouzidi_cells, "cells": int(sum(g.n_blocks for g in setup[0]) * 512),
         "cell_updates_per_coarse_step": int(work), "setup_s": round(t_setup, 1), "run_s": round(t_run, 1),
         "ms_per_coarse_step_incl_diagnostics": round(t_run / total * 1e3, 4),
+        # between diagnostics rows, the first interval (device set-up, first-launch costs) left out
+        "ms_per_coarse_step_steady": (round((stamps[-1] - stamps[0]) / ((len(stamps) - 1) * diag_freq) * 1e3, 4) if len(stamps) > 1 else None),
+        "glups_true_count_steady": (round(work * (len(stamps) - 1) * diag_freq / (stamps[-1] - stamps[0]) / 1e9, 3) if len(stamps) > 1 else None),
         "glups_true_count_incl_diagnostics": round(work * total / t_run / 1e9, 3),
         "frac_of_8TBs_at_216B_incl_diagnostics": round(work * total / t_run * 216 / 8e12, 4),
         "all_finite": bool(np.isfinite(a).all()), "rho_min_over_run": float(a[:, 2].min()), "rho_min_last_row": float(a[-1, 2]),
