@@ -249,3 +249,25 @@ def test_real_wing_on_ranks_equals_single_device(gpu, wing_real, tmp_path, world
     for lvl in range(3):                 # every level cut on its own into near-equal parts (planar cuts at block granularity)
         owned = [s[lvl][0] for s in stats]
         assert sum(owned) == [2090, 1728, 5256][lvl] and max(owned) <= 1.15 * sum(owned) / world, owned
+
+
+@pytest.mark.gpu
+def test_wing_exactly_as_shipped_sets_up_and_steps(gpu):
+    """CASES/Wing_5_deg/config.yaml with NO overrides - num_levels 5, surface_resolution 1100: 151 020 blocks, 77.3 M cells, 2.1 M Bouzidi
+    cells, the finest level above the 32-bit address limit of a level (the WIDE instantiations). Native set-up, 24 coarse steps (24 G cell
+    updates) through run_case: the set-up integers (pinned against the numpy restatement in profiles/r03_native_setup_vs_numpy.txt; the
+    reference holds no wing log: parity unpinned), finite coefficients, a density that stays at rest level this early in the ramp.
+    HIP = oracle at this size is a one-off (tools/wing_shipped_oracle_check.py, profiles/r03_wing5deg_as_shipped_hip_equals_oracle.txt)."""
+    cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"))
+    assert (cfg.num_levels, cfg.surface_resolution, cfg.steps, cfg.ramp_steps) == (5, 1100, 10000, 2000)
+    cfg.diag_freq = 8
+    setup = pp.setup_multilevel_domain(cfg, os.path.join(G, "wing5deg_model.stl"))
+    rep = setup[3]
+    assert rep.level_blocks == [5460, 2624, 8328, 28008, 106600] and rep.bouzidi_cells == [2109221]
+    assert rep.flood_fill_filled == [890, 15530, 164099, 1488698, 12673840] and rep.near_wall_cells == [5146, 18661, 69950, 272616, 1073087]
+    assert setup[0][-1].n_blocks * 512 * 27 * 4 > 2 ** 32, "the finest level's population array needs 64-bit offsets"
+    rows, _, _ = case.run_case(cfg, case.HipStepper, steps=24, setup=setup)
+    assert [r.step for r in rows] == [8, 16, 24]
+    a = np.array([[r.rho_min, r.cd, r.cl, r.cmy] for r in rows])
+    assert np.isfinite(a).all() and (a[:, 0] > 0.9999).all() and (a[:, 0] <= 1.0).all()
+    assert np.abs(a[-1, 1:]).max() > 0, "the ramp has started: the coefficients are not identically zero"
