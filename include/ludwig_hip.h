@@ -83,8 +83,9 @@ typedef struct LudwigLevelHost {
     const float   *sponge;         /* optional */
     const float   *wall_dist;      /* optional */
     int32_t enable_temporal_interpolation;        /* allocate f_old/rho_old/vel_old (src/blocks.jl:123-142) */
-    int32_t n_boundary_cells;      /* > 0 with a q map enables Bouzidi (src/blocks.jl:152); < 0: no cells here, but store
-                                      f_post_collision anyway (multi-GPU: a peer's Bouzidi cells read this rank's face layer) */
+    int32_t n_boundary_cells;      /* > 0 with a q map enables Bouzidi (src/blocks.jl:152); < 0: no cells here, but allocate and
+                                      store f_post_collision anyway (multi-GPU: a peer's Bouzidi cells read this rank's face layer) -
+                                      in every block, until ludwig_level_add_post_collision_readers says where it is read */
     const uint16_t *bouzidi_q_map; /* Float16 bits [8,8,8,nb,27]; optional                          */
     const int32_t  *bouzidi_cell_block;           /* [n_boundary_cells] 1-based                     */
     const int8_t   *bouzidi_cell_x, *bouzidi_cell_y, *bouzidi_cell_z;   /* 1-based local coords     */
@@ -125,6 +126,14 @@ void ludwig_level_destroy(LudwigLevel *level);
 
 /* HIP stream (hipStream_t) all later calls on this level are queued on; NULL = the null stream. */
 int  ludwig_level_set_stream(LudwigLevel *level, void *hip_stream);
+
+/* Multi-GPU, Bouzidi levels: name the f_post_collision elements somebody OUTSIDE this level's own cell list reads - a peer rank's
+ * Bouzidi links reach one cell across a cut (src/bouzidi_kernel.jl:47-58), i.e. exactly the elements of this rank's group-2 send
+ * lists (ludwig_halo_plan_create). offsets: element offsets into f_post_collision in the reference layout [8,8,8,n_blocks,27], like the
+ * halo index lists. The library adds their x-rows to the rows the stream-collide step stores (store_post_collision_everywhere above);
+ * a level created with n_boundary_cells < 0 stops storing every block from the first call on (n = 0 is a valid call: nobody reads).
+ * No effect on a level created with store_post_collision_everywhere = 1. May be called again; the sets add up. Synchronizes the stream. */
+int  ludwig_level_add_post_collision_readers(LudwigLevel *level, const int64_t *offsets, int64_t n);
 
 /*
  * A HIP stream whose kernels may use every compute unit of `device` except `reserved_cus` of them (0 = an ordinary stream).

@@ -132,6 +132,14 @@ function Comm(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)
     return Comm(out[])
 end
 destroy!(c::Comm) = ccall((:ludwig_comm_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.handle)
+"""
+Bouzidi level cut over ranks: the f_post_collision elements a PEER's links read across the cut (= this rank's group-2 send list,
+0-based element offsets in the [8,8,8,n_blocks,27] layout). The step then stores the rows with a reader instead of every block.
+"""
+function add_post_collision_readers!(d::DeviceLevel, offsets::Vector{Int64})
+    GC.@preserve offsets check(ccall((:ludwig_level_add_post_collision_readers, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int64),
+                                     d.handle, isempty(offsets) ? Ptr{Int64}(C_NULL) : pointer(offsets), Int64(length(offsets))))
+end
 """in-place all-reduce of a few Float32 diagnostics (op 0 sum, 2 max, 3 min): rho_min, the nine force sums"""
 allreduce!(c::Comm, v::Vector{Float32}, op::Integer) =
     GC.@preserve v check(ccall((:ludwig_comm_allreduce_f32, LIB), Cint, (Ptr{Cvoid}, Ptr{Cfloat}, Int32, Int32), c.handle, pointer(v), Int32(length(v)), Int32(op)))

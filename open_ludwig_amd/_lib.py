@@ -24,7 +24,7 @@ PART_ALL, PART_BOUNDARY, PART_INTERIOR = 0, 1, 2
 # every symbol include/ludwig_hip.h declares (tests check the .so exports exactly these)
 EXPORTED_SYMBOLS = [
     "ludwig_abi_version", "ludwig_last_error", "ludwig_device_count",
-    "ludwig_level_create", "ludwig_level_destroy", "ludwig_level_set_stream", "ludwig_level_set_order",
+    "ludwig_level_create", "ludwig_level_destroy", "ludwig_level_set_stream", "ludwig_level_add_post_collision_readers", "ludwig_level_set_order",
     "ludwig_level_upload", "ludwig_level_download", "ludwig_level_field_ptr",
     "ludwig_init_equilibrium", "ludwig_step", "ludwig_stream_collide", "ludwig_bouzidi_correction",
     "ludwig_save_old", "ludwig_execute_timestep_batch", "ludwig_sync", "ludwig_halo_pack", "ludwig_halo_unpack", "ludwig_level_info",
@@ -113,6 +113,7 @@ def load() -> C.CDLL:
         "ludwig_level_create": (C.c_int, [C.POINTER(LevelHost), i32, C.POINTER(vp)]),
         "ludwig_level_destroy": (None, [vp]),
         "ludwig_level_set_stream": (C.c_int, [vp, vp]),
+        "ludwig_level_add_post_collision_readers": (C.c_int, [vp, vp, i64]),
         "ludwig_level_set_order": (C.c_int, [vp, i32, vp, i64]),
         "ludwig_level_upload": (C.c_int, [vp, i32, vp, C.c_size_t]),
         "ludwig_level_download": (C.c_int, [vp, i32, vp, C.c_size_t]),

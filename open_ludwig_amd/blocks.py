@@ -215,7 +215,10 @@ class DeviceLevel:
         h.wall_dist = ptr(host.wall_dist, np.float32) if (host.wall_dist != 100.0).any() else None
         h.enable_temporal_interpolation = 1 if host.f_old.size > 27 else 0
         h.n_boundary_cells = host.n_boundary_cells
-        if getattr(host, "force_post_collision", False) and host.n_boundary_cells == 0:
+        # multi-GPU, Bouzidi level: `post_collision_readers` (element offsets into f_post_collision that a PEER reads - this rank's
+        # f_post send lists) narrows the store to the rows with a reader; without it `force_post_collision` stores every block
+        readers = getattr(host, "post_collision_readers", None)
+        if (getattr(host, "force_post_collision", False) or readers is not None) and host.n_boundary_cells == 0:
             h.n_boundary_cells = -1        # multi-GPU: store f_post_collision although no Bouzidi cell is owned here
         if host.bouzidi_enabled:
             h.bouzidi_q_map = ptr(host.bouzidi_q_map.view(np.uint16))
@@ -225,10 +228,12 @@ class DeviceLevel:
             h.bouzidi_cell_z = ptr(host.bouzidi_cell_z, np.int8)
         if host.comm_boundary is not None:
             h.comm_boundary = ptr(host.comm_boundary, np.uint8)
-        h.store_post_collision_everywhere = 1 if getattr(host, "force_post_collision", False) else 0
+        h.store_post_collision_everywhere = 1 if (getattr(host, "force_post_collision", False) and readers is None) else 0
         handle = C.c_void_p()
         _lib.check(lib.ludwig_level_create(C.byref(h), device, C.byref(handle)))
         self._h = handle
+        if readers is not None and self.n_blocks > 0:
+            self.add_post_collision_readers(readers)
         # state: the constructor defaults already match; copy whatever the host level holds
         if self.n_blocks == 0 or not upload_state:
             return
@@ -270,6 +275,11 @@ class DeviceLevel:
     @property
     def has_post_collision(self) -> bool:
         return bool(self.info().has_post_collision)
+
+    def add_post_collision_readers(self, offsets: np.ndarray) -> None:
+        """f_post_collision elements read from outside this level's own cell list (a peer's links across a cut): their x-rows join the store"""
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        _lib.check(self._lib.ludwig_level_add_post_collision_readers(self.handle, o.ctypes.data if o.size else None, o.size))
 
     def set_stream(self, hip_stream: int) -> None:
         _lib.check(self._lib.ludwig_level_set_stream(self.handle, C.c_void_p(hip_stream)))

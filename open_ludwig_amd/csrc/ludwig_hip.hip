@@ -78,6 +78,9 @@ struct LudwigLevel {
     int4 *bouzidi_links = nullptr;      // every listed link with q > 0 (the q map is static): kernels.hpp BouzidiParams::links
     int n_bouzidi_links = 0;
     uint32_t *post_rows = nullptr;      // [n_blocks][2] bits: the x-rows f_post_collision is read at by the links with q > 0 (SCParams::post_rows)
+    std::vector<uint32_t> h_post_rows;  // host copy (ludwig_level_add_post_collision_readers ORs into it)
+    int post_mode = 0;                  // 0: rows / blocks with a reader; 1: every block because asked to (flag, environment);
+                                        // 2: every block because no cell list is owned and nobody has named the readers yet
     bool post_rows_used = false;        // the last stream-collide stored f_post_collision by rows (valid for q_min >= 0 only)
     _Float16 *q_map = nullptr;
     int32_t *cell_block = nullptr;
@@ -1304,7 +1307,9 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             // where f_post_collision has a reader: blocks that hold a Bouzidi cell or a cell next to one (a link q < 1/2 reads
             // the cell one step behind, possibly across a block face). No cell list on this rank (forced store, multi-GPU:
             // the readers are a peer's cells), store_post_collision_everywhere or LUDWIG_FULL_POST_COLLISION set: every block, as the reference.
-            const bool everywhere = L->n_bc == 0 || h->store_post_collision_everywhere != 0 || getenv("LUDWIG_FULL_POST_COLLISION") != nullptr;
+            const bool fixed = h->store_post_collision_everywhere != 0 || getenv("LUDWIG_FULL_POST_COLLISION") != nullptr;
+            const bool everywhere = L->n_bc == 0 || fixed;
+            L->post_mode = fixed ? 1 : (L->n_bc == 0 ? 2 : 0);
             for (int b = 0; b < L->n_blocks && everywhere; ++b) L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
             for (int i = 0; i < L->n_bc && !everywhere; ++i) {
                 // the cell itself and the 26 cells around it (a link reads f_post one cell behind the boundary cell)
@@ -1320,12 +1325,14 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
             // inside those blocks: the x-rows a link with q > 0 reads - its own cell and the cell one step behind
             // (LUDWIG_POST_ROWS=0: whole blocks, round 2's granularity)
             const char *pr = getenv("LUDWIG_POST_ROWS");
-            if (!everywhere && !bl.empty() && !(pr && pr[0] == '0')) {
-                std::vector<uint32_t> rows((size_t)L->n_blocks * 2, 0u);
-                auto mark = [&](int cell) { const int row = (cell & (CELLS - 1)) >> 3; rows[(size_t)(cell / CELLS) * 2 + (row >> 5)] |= 1u << (row & 31); };
+            if (!fixed && !(pr && pr[0] == '0')) {
+                L->h_post_rows.assign((size_t)L->n_blocks * 2, 0u);
+                auto mark = [&](int cell) { const int row = (cell & (CELLS - 1)) >> 3; L->h_post_rows[(size_t)(cell / CELLS) * 2 + (row >> 5)] |= 1u << (row & 31); };
                 for (const int4 &l : bl) { mark(l.x); if (l.w >= 0) mark(l.w); }
-                LW_HIP(hipMalloc((void **)&L->post_rows, rows.size() * 4));
-                LW_HIP(hipMemcpy(L->post_rows, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+                if (!everywhere) {
+                    LW_HIP(hipMalloc((void **)&L->post_rows, L->h_post_rows.size() * 4));
+                    LW_HIP(hipMemcpy(L->post_rows, L->h_post_rows.data(), L->h_post_rows.size() * 4, hipMemcpyHostToDevice));
+                }
             }
         }
         LW_HIP(hipStreamSynchronize(L->stream));
@@ -1340,6 +1347,37 @@ static int level_create_impl(const LudwigLevelHost *h, int device, LudwigLevel *
 #undef LW_TRY
     *out = L;
     return LUDWIG_OK;
+}
+
+int ludwig_level_add_post_collision_readers(LudwigLevel *L, const int64_t *offsets, int64_t n)
+{
+    if (!L || (!offsets && n > 0) || n < 0) return fail(LUDWIG_ERR_INVALID, "null argument");
+    if (!L->has_post) return fail(LUDWIG_ERR_STATE, "level %d has no f_post_collision", L->level_id);
+    if (L->post_mode == 1 || L->n_blocks == 0) return LUDWIG_OK;      // every block is stored already, and stays so
+    LW_HIP(hipSetDevice(L->device));
+    LW_HIP(hipStreamSynchronize(L->stream));
+    const int64_t sk = (int64_t)L->n_blocks * CELLS;
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i] < 0 || offsets[i] >= sk * Q) return fail(LUDWIG_ERR_INVALID, "reader offset %lld outside f_post_collision", (long long)i);
+    if (L->post_mode == 2) {             // "everything, because nobody said who reads": now somebody has
+        for (int b = 0; b < L->n_blocks; ++b) L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] &= ~FLAG_STORE_POST;
+        L->post_mode = 0;
+    }
+    const bool by_rows = !L->h_post_rows.empty();
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t e = offsets[i] % sk;
+        int b = (int)(e / CELLS);
+        if (!L->ref2int.empty()) b = L->ref2int[b];
+        const int row = (int)(e % CELLS) >> 3;
+        L->h_meta[(size_t)b * NBR_STRIDE + NBR_FLAGS] |= FLAG_STORE_POST;
+        if (by_rows) L->h_post_rows[(size_t)b * 2 + (row >> 5)] |= 1u << (row & 31);
+    }
+    if (by_rows) {
+        if (!L->post_rows) LW_HIP(hipMalloc((void **)&L->post_rows, L->h_post_rows.size() * 4));
+        LW_HIP(hipMemcpy(L->post_rows, L->h_post_rows.data(), L->h_post_rows.size() * 4, hipMemcpyHostToDevice));
+    }
+    ++L->version;
+    return upload_meta(L);
 }
 
 int ludwig_level_set_stream(LudwigLevel *L, void *hip_stream)
