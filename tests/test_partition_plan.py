@@ -268,3 +268,34 @@ def test_eight_rank_layout_has_three_equal_face_peers_and_no_x_face():
     # the boundary part is whole x rows: widening to groups of 4 adds nothing
     plain = partition.build_local_level(1, coords, table, owner, 5, 0.5006)
     assert np.array_equal(plain.level.comm_boundary, view.level.comm_boundary)
+
+
+def test_post_collision_readers_are_the_f_post_send_lists():
+    """A Bouzidi level cut in two through the body: what a rank must keep of f_post_collision for OTHERS is exactly what its plan sends
+    in the f_post group, and every such element is the cell one step behind a peer's link with 0 < q < 1/2 (src/bouzidi_kernel.jl:47-58).
+    `name_post_collision_readers` hands that list to the level (DeviceLevel passes it to ludwig_level_add_post_collision_readers)."""
+    grids, params = cases.tunnel_with_sphere((6, 4, 4), levels=1, wall_model=False)
+    g = grids[0]
+    bx = np.asarray(g.active_block_coords)[:, 0]
+    owner = (bx > bx.min() + 2).astype(np.int64)            # the cut runs through the sphere's blocks
+    views = []
+    for r in range(2):
+        v = partition.build_local_level(1, g.active_block_coords, g.neighbor_table, owner, r, float(g.tau), temporal=g.f_old.size > 27)
+        partition.slice_level_fields(v, g)
+        views.append(v)
+    reqs = [partition.make_requests(v, g.n_blocks, partition.compute_needs(v)) for v in views]
+    plans = [partition.build_plan(views[r], g.n_blocks, reqs[r], {q: reqs[q][r] for q in range(2) if r in reqs[q]}) for r in range(2)]
+    assert all(v.level.force_post_collision for v in views) and any(p.has("f_post") for p in plans)
+    total = 0
+    for r, (v, p) in enumerate(zip(views, plans)):
+        partition.name_post_collision_readers(v.level, p)
+        readers = v.level.post_collision_readers
+        want = np.concatenate([np.asarray(p.send[q]["f_post"], dtype=np.int64) for q in p.peers]) if p.peers else np.zeros(0, np.int64)
+        assert np.array_equal(np.sort(readers), np.sort(want))
+        # every named element lies in an OWNED block of this rank and is what the peer receives
+        blk = (readers % (v.level.n_blocks * 512)) // 512
+        assert (blk < v.n_owned).all()
+        for q in p.peers:
+            assert len(p.send[q]["f_post"]) == len(plans[q].recv[r]["f_post"])
+        total += readers.size
+    assert total > 0, "no link reaches across the cut: the case does not exercise the readers"
