@@ -16,7 +16,7 @@ from typing import List, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LUDWIG_ORACLE_LIB") or os.path.join(_HERE, "libludwig_oracle.so")   # override: tools/oracle_contraction.py only
+LIB_PATH = os.environ.get("LUDWIG_ORACLE_LIB") or os.path.join(_HERE, "libludwig_oracle.so")   # override: tests/oneoff_oracle_contraction.py only
 
 
 class OracleLevel(C.Structure):

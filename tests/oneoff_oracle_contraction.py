@@ -3,7 +3,7 @@ step 200, this repository 0.0637 / 1004.04 - 0.6 % - while every later row agree
 runs, whose compiler fuses a*b+c; the oracle and the HIP kernels never do. This script steps the CPU oracle on ball1m to
 step N in two builds of the SAME source - contraction off (the parity build) and -ffp-contract=fast -mfma - and prints
 the force rows, so the size of the effect of fusing is measured instead of asserted.
-usage: oracle_contraction.py re266k|re10m [steps=200] [threads]   (run once per flavour: LUDWIG_ORACLE_LIB selects the build)"""
+usage: tests/oneoff_oracle_contraction.py re266k|re10m [steps=200] [threads]   (run once per flavour: LUDWIG_ORACLE_LIB selects the build)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

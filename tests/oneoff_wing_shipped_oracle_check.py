@@ -6,7 +6,7 @@ after 2 coarse steps the ramp's own value would be 1e-8 and the comparison next 
 the refinement interfaces meet a real flow from the first step on, where from rest the finest levels see 1e-6 in two steps (the inlet is
 50 coarse cells away). Too slow for the GPU suite (the oracle needs most of a minute per coarse step on 16 cores), so it lives here and its
 output is kept under profiles/.
-usage: wing_shipped_oracle_check.py [coarse steps = 2] [uniform | rest]"""
+usage: tests/oneoff_wing_shipped_oracle_check.py [coarse steps = 2] [uniform | rest]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

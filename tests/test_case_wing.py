@@ -257,7 +257,7 @@ def test_wing_exactly_as_shipped_sets_up_and_steps(gpu):
     cells, the finest level above the 32-bit address limit of a level (the WIDE instantiations). Native set-up, 24 coarse steps (24 G cell
     updates) through run_case: the set-up integers (pinned against the numpy restatement in profiles/r03_native_setup_vs_numpy.txt; the
     reference holds no wing log: parity unpinned), finite coefficients, a density that stays at rest level this early in the ramp.
-    HIP = oracle at this size is a one-off (tools/wing_shipped_oracle_check.py, profiles/r03_wing5deg_as_shipped_hip_equals_oracle.txt)."""
+    HIP = oracle at this size is a one-off (tests/oneoff_wing_shipped_oracle_check.py, profiles/r03_wing5deg_as_shipped_hip_equals_oracle.txt)."""
     cfg = pp.load_case_configuration(os.path.join(G, "wing5deg_config.yaml"))
     assert (cfg.num_levels, cfg.surface_resolution, cfg.steps, cfg.ramp_steps) == (5, 1100, 10000, 2000)
     cfg.diag_freq = 8

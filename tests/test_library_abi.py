@@ -69,17 +69,18 @@ def test_error_reporting_without_device():
 
 
 def test_product_package_never_imports_the_oracle():
-    """No file of the product package imports, loads or links anything under oracle/ (comments may mention it)."""
-    pkg = os.path.join(ROOT, "open_ludwig_amd")
+    """No file of the product package - and none of the measurement helpers under tools/, the Julia binding or the headers - imports,
+    loads or links anything under oracle/ (comments may mention it). Checkers that do live under tests/ (test_*.py, oneoff_*.py)."""
     bad = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)|libludwig_oracle|ludwig_oracle\.h|oracle[/\\]", re.M)
-    for dirpath, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
-                src = open(os.path.join(dirpath, f)).read()
-                code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
-                code = re.sub(r'\"\"\".*?\"\"\"', "", code, flags=re.S)
-                m = bad.search(code)
-                assert m is None, (os.path.join(dirpath, f), m.group(0))
+    for top in ("open_ludwig_amd", "tools", "julia", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h", ".sh", ".jl")):
+                    src = open(os.path.join(dirpath, f)).read()
+                    code = "\n".join(l for l in src.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
+                    code = re.sub(r'\"\"\".*?\"\"\"', "", code, flags=re.S)
+                    m = bad.search(code)
+                    assert m is None, (os.path.join(dirpath, f), m.group(0))
 
 
 # ---- the header as a C99 translation unit: struct layouts against the ctypes and Julia mirrors, calls through dlopen ----
