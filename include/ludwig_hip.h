@@ -310,6 +310,11 @@ int  ludwig_halo_wait(LudwigHaloPlan *plan);
 int  ludwig_halo_plan_pack(LudwigHaloPlan *plan, int32_t group, int32_t field, void *hip_stream);
 int  ludwig_halo_plan_unpack(LudwigHaloPlan *plan, int32_t group, int32_t field, void *hip_stream);
 int  ludwig_halo_plan_buffers(const LudwigHaloPlan *plan, int32_t group, void **send_dev, int64_t *n_send, void **recv_dev, int64_t *n_recv);
+/* In-stream mode: ludwig_halo_exchange queues pack, transfer and unpack on the LEVEL's stream instead of the plan's own - no overlap
+ * with what the level launches next, and no cross-stream hand-over either (each costs the device tens of idle microseconds: more than
+ * the whole exchange of a small level; nested levels take 2^(l-1) steps per coarse step). ludwig_halo_wait is then a no-op. The Python
+ * host chooses it for levels below 8 192 owned blocks (LUDWIG_HALO_IN_STREAM_BELOW). Same messages, same bits. */
+int  ludwig_halo_plan_in_stream(LudwigHaloPlan *plan, int enable);
 /* Benchmarks: with timing on, every ludwig_halo_exchange is bracketed by events on the plan's stream (the span includes waiting beside
  * whatever the device is busy with); ludwig_halo_plan_exchange_ms returns the spans of the exchanges finished since the last call
  * (at most `max`, oldest first; call after a device synchronize). */

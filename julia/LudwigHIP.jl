@@ -132,6 +132,8 @@ function Comm(id::Vector{UInt8}, rank::Integer, world::Integer, device::Integer)
     return Comm(out[])
 end
 destroy!(c::Comm) = ccall((:ludwig_comm_destroy, LIB), Cvoid, (Ptr{Cvoid},), c.handle)
+"""small levels: queue the exchange on the level's own stream (no overlap, no cross-stream hand-over; `wait!` becomes a no-op)"""
+in_stream!(p, on::Bool) = check(ccall((:ludwig_halo_plan_in_stream, LIB), Cint, (Ptr{Cvoid}, Cint), p.handle, Cint(on)))
 """
 Bouzidi level cut over ranks: the f_post_collision elements a PEER's links read across the cut (= this rank's group-2 send list,
 0-based element offsets in the [8,8,8,n_blocks,27] layout). The step then stores the rows with a reader instead of every block.

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "ludwig_stream_create", "ludwig_stream_destroy", "ludwig_level_field_layout", "ludwig_level_set_rho_store",
     "ludwig_comm_unique_id", "ludwig_comm_create", "ludwig_comm_destroy", "ludwig_comm_allreduce_f32",
     "ludwig_halo_plan_create", "ludwig_halo_plan_destroy", "ludwig_halo_exchange", "ludwig_halo_wait",
-    "ludwig_halo_plan_pack", "ludwig_halo_plan_unpack", "ludwig_halo_plan_buffers", "ludwig_halo_plan_timing",
+    "ludwig_halo_plan_pack", "ludwig_halo_plan_unpack", "ludwig_halo_plan_buffers", "ludwig_halo_plan_timing", "ludwig_halo_plan_in_stream",
     "ludwig_halo_plan_exchange_ms", "ludwig_step_distributed",
 ]
 UNIQUE_ID_BYTES = 128
@@ -147,6 +147,7 @@ def load() -> C.CDLL:
         "ludwig_halo_plan_unpack": (C.c_int, [vp, i32, i32, vp]),
         "ludwig_halo_plan_buffers": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)]),
         "ludwig_halo_plan_timing": (C.c_int, [vp, i32]),
+        "ludwig_halo_plan_in_stream": (C.c_int, [vp, i32]),
         "ludwig_halo_plan_exchange_ms": (C.c_int, [vp, vp, i32, C.POINTER(C.c_int32)]),
         "ludwig_step_distributed": (C.c_int, [vp, vp, vp, i64, f32, f32, f32, C.POINTER(StepFlags)]),
     }

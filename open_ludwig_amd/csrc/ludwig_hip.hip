@@ -2028,6 +2028,7 @@ struct LudwigHaloPlan {
     bool pending = false;                              // an exchange has been queued since the last wait
     bool self_via_rccl = false;                        // LUDWIG_HALO_SELF_VIA_RCCL: messages to this rank itself go through ncclSend / ncclRecv
     bool timing = false;
+    bool in_stream = false;                            // ludwig_halo_plan_in_stream: the exchange runs ON the level's stream (no event hand-over)
     hipEvent_t t0[TIMING_RING] = {}, t1[TIMING_RING] = {};
     int64_t n_timed = 0, n_read = 0;
 };
@@ -2277,6 +2278,17 @@ int ludwig_halo_plan_timing(LudwigHaloPlan *P, int enable)
     return LUDWIG_OK;
 }
 
+int ludwig_halo_plan_in_stream(LudwigHaloPlan *P, int enable)
+{
+    if (!P) return fail(LUDWIG_ERR_INVALID, "null plan");
+    if (P->pending) {                    // an exchange of the other kind is in flight: the level's stream joins it first
+        const int r = ludwig_halo_wait(P);
+        if (r) return r;
+    }
+    P->in_stream = enable != 0;
+    return LUDWIG_OK;
+}
+
 int ludwig_halo_plan_exchange_ms(LudwigHaloPlan *P, float *ms_out, int32_t max, int32_t *n_out)
 {
     if (!P || !n_out || (max > 0 && !ms_out)) return fail(LUDWIG_ERR_INVALID, "null argument");
@@ -2341,13 +2353,25 @@ int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, co
         const int r = halo_prepare_field(L, groups[i], fields[i]);     // may queue work on the level's stream: before the event below
         if (r) return r;
     }
+    // nothing to send or to receive in these groups (a level this rank shares with nobody): no event, no kernel
+    {
+        int64_t moved = 0;
+        for (int i = 0; i < n; ++i) moved += P->g[groups[i]].n_send + P->g[groups[i]].n_recv;
+        if (moved == 0) return LUDWIG_OK;
+    }
     ++L->version;
-    LW_HIP(hipEventRecord(P->ev_ready, L->stream));
-    LW_HIP(hipStreamWaitEvent(P->s_comm, P->ev_ready, 0));
+    // in-stream mode: pack, transfer and unpack are queued on the level's own stream - what follows on that stream follows the exchange,
+    // at the price of no overlap and to the gain of two cross-stream hand-overs (tens of microseconds of idle device each, more than a
+    // small level's whole exchange)
+    const hipStream_t xs = P->in_stream ? L->stream : P->s_comm;
+    if (!P->in_stream) {
+        LW_HIP(hipEventRecord(P->ev_ready, L->stream));
+        LW_HIP(hipStreamWaitEvent(P->s_comm, P->ev_ready, 0));
+    }
     const int slot = (int)(P->n_timed % TIMING_RING);
-    if (P->timing) LW_HIP(hipEventRecord(P->t0[slot], P->s_comm));
+    if (P->timing) LW_HIP(hipEventRecord(P->t0[slot], xs));
     for (int i = 0; i < n; ++i) {
-        const int r = halo_pack_group(P, groups[i], fields[i], P->s_comm);
+        const int r = halo_pack_group(P, groups[i], fields[i], xs);
         if (r) return r;
     }
     if (trace) h1 = host_now_us();
@@ -2364,22 +2388,24 @@ int ludwig_halo_exchange(LudwigHaloPlan *P, int32_t n, const int32_t *groups, co
             const int64_t s0 = G.send_off[p], ns = G.send_off[p + 1] - s0, r0 = G.recv_off[p], nr = G.recv_off[p + 1] - r0;
             if (self) {
                 if (ns != nr) return fail(LUDWIG_ERR_INVALID, "peer %zu is this rank itself but sends %lld and receives %lld elements", p, (long long)ns, (long long)nr);
-                if (ns) LW_HIP(hipMemcpyAsync(G.recv_buf + r0, G.send_buf + s0, (size_t)ns * 4, hipMemcpyDeviceToDevice, P->s_comm));
+                if (ns) LW_HIP(hipMemcpyAsync(G.recv_buf + r0, G.send_buf + s0, (size_t)ns * 4, hipMemcpyDeviceToDevice, xs));
             } else {
-                if (ns) LW_NCCL(api, api->Send(G.send_buf + s0, (size_t)ns, ncclFloat, P->peers[p], P->comm->comm, P->s_comm));
-                if (nr) LW_NCCL(api, api->Recv(G.recv_buf + r0, (size_t)nr, ncclFloat, P->peers[p], P->comm->comm, P->s_comm));
+                if (ns) LW_NCCL(api, api->Send(G.send_buf + s0, (size_t)ns, ncclFloat, P->peers[p], P->comm->comm, xs));
+                if (nr) LW_NCCL(api, api->Recv(G.recv_buf + r0, (size_t)nr, ncclFloat, P->peers[p], P->comm->comm, xs));
             }
         }
     }
     if (any_remote) LW_NCCL(api, api->GroupEnd());
     if (trace) h2 = host_now_us();
     for (int i = 0; i < n; ++i) {
-        const int r = halo_unpack_group(P, groups[i], fields[i], P->s_comm);
+        const int r = halo_unpack_group(P, groups[i], fields[i], xs);
         if (r) return r;
     }
-    if (P->timing) { LW_HIP(hipEventRecord(P->t1[slot], P->s_comm)); ++P->n_timed; }
-    LW_HIP(hipEventRecord(P->ev_done, P->s_comm));
-    P->pending = true;
+    if (P->timing) { LW_HIP(hipEventRecord(P->t1[slot], xs)); ++P->n_timed; }
+    if (!P->in_stream) {
+        LW_HIP(hipEventRecord(P->ev_done, P->s_comm));
+        P->pending = true;
+    }
     if (trace) fprintf(stderr, "[ludwig_halo_exchange] host us: events + pack %.1f, send/recv group (%zu peers) %.1f, unpack + event %.1f\n", h1 - h0, P->peers.size(), h2 - h1, host_now_us() - h2);
     return LUDWIG_OK;
 }

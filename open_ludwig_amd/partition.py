@@ -426,6 +426,7 @@ class NativeHalo:
         _lib.check(lib.ludwig_halo_plan_create(level.handle, comm, C.byref(d), C.byref(h)))
         self._h = h
         self._timing = False
+        self.in_stream = False
 
     @property
     def handle(self):
@@ -442,6 +443,11 @@ class NativeHalo:
     def join(self) -> None:
         """what is queued on the level's stream from here on runs after the last posted exchange"""
         self._lib.check(self._lib.load().ludwig_halo_wait(self._h))
+
+    def set_in_stream(self, on: bool) -> None:
+        """the exchange on the level's own stream (no overlap, no cross-stream hand-over): ludwig_halo_plan_in_stream"""
+        self._lib.check(self._lib.load().ludwig_halo_plan_in_stream(self._h, 1 if on else 0))
+        self.in_stream = bool(on)
 
     @property
     def timing(self) -> bool:
@@ -1019,13 +1025,26 @@ class MultiLevelRunner:
                     import sys
                     print(f"[ludwig] native RCCL communicator unavailable ({e}); halo exchange falls back to torch.distributed", file=sys.stderr, flush=True)
                     self.transport = "torch"
+        # per level: is hiding the exchange behind part of the level's own step worth two cross-stream hand-overs and two launches
+        # instead of one? Only where a level step is long against them - nested levels take 2^(l-1) steps per coarse step, most of them
+        # on levels of a few thousand blocks whose whole exchange is shorter than one hand-over (tools/multilevel_runner_host_cost.py).
+        # Below LUDWIG_HALO_IN_STREAM_BELOW owned blocks (default 8 192 = 4.2 M cells, ~0.2 ms of stepping - the size below which the
+        # library also merges a level's launches) the native exchange is queued on the level's own stream and the level is stepped in
+        # one launch; a level this rank shares with nobody likewise. RCCL loop-back, two nested levels (profiles/
+        # r03_nested_loopback_in_stream_ab.txt): 64 + 256 owned blocks 0.25 -> 0.17 ms per coarse step, 1 728 + 2 304 a wash.
+        below = int(os.environ.get("LUDWIG_HALO_IN_STREAM_BELOW", "8192"))
+        self.level_overlap = [bool(overlap)] * len(plans)
         if self.transport == "native":
             for i, plan in enumerate(plans):
                 if self.levels[i] is None:
                     assert not plan.peers, "a level without a local copy exchanges nothing"
                     self.ex.append(None)
                 else:
-                    self.ex.append(NativeHalo(plan, self.levels[i], self.comm, wire_ranks[i] if wire_ranks else None))
+                    hx = NativeHalo(plan, self.levels[i], self.comm, wire_ranks[i] if wire_ranks else None)
+                    if overlap and (not plan.peers or self.views[i].n_owned < below):
+                        hx.set_in_stream(True)
+                        self.level_overlap[i] = False
+                    self.ex.append(hx)
             self.s_comm = None
         else:
             self.s_comm = torch.cuda.Stream(self.dev, priority=-1) if overlap else self.s_comp      # see init_rccl
@@ -1075,7 +1094,7 @@ class MultiLevelRunner:
         has_post_halo = plan is not None and plan.has("f_post")
         if i > 0:
             self._join(i - 1)                                # the parent's ghosts (interpolation stencils) must be in place
-        if not self.overlap:
+        if not self.level_overlap[i]:
             if stepping:
                 stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
             if has_post_halo:

@@ -142,7 +142,8 @@ def nested_main(grid, nb, steps, out_path, transport):
     rep = {"backend": dist.get_backend(), "transport": transport, "nested": True, "grid": list(grid),
            "blocks": [int(g.n_blocks) for g in grids], "owned": [int(v.n_owned) for v in runner.views],
            "halo_bytes_per_level": [int(pl.bytes_per_step()) for pl in runner.plans],
-           "parent_data_in_level1_halo": bool(runner.plans[0].has("rho"))}
+           "parent_data_in_level1_halo": bool(runner.plans[0].has("rho")),
+           "exchange_in_stream": [bool(getattr(ex, "in_stream", False)) for ex in runner.ex]}
     # ghosts of the start state, fetched the way every later one is
     for i, ex in enumerate(runner.ex):
         for fields in ({"f": "f", "vel": "vel"}, {"f": "f_temp", "vel": "vel_temp"}):
@@ -150,9 +151,11 @@ def nested_main(grid, nb, steps, out_path, transport):
                 fields = dict(fields, rho="rho")
             ex.post(fields); ex.join()
     runner.synchronize()
+    t0 = time.perf_counter()
     for t in range(1, steps + 1):
         runner.step(t)
     runner.synchronize()
+    rep["ms_per_coarse_step_wall"] = (time.perf_counter() - t0) / steps * 1e3
     nb3 = (nb, nb, nb) if isinstance(nb, int) else tuple(nb)
     one, _, params1, _ = nested_symmetric_bricks((1, 1, 1), nb3)
     dev = [adapt(g, 0) for g in one]

@@ -120,7 +120,7 @@ def test_native_exchange_with_device_copies(gpu, overlap):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("grid,steps,transport", [("2x1x1", 4, "native"), ("4x1x1", 3, "native"), ("2x1x1", 4, "torch")])
+@pytest.mark.parametrize("grid,steps,transport", [("2x1x1", 4, "native"), ("4x1x1", 3, "native"), ("2x1x1", 4, "native-overlap"), ("2x1x1", 4, "torch")])
 def test_nested_levels_over_rccl_loopback(gpu, tmp_path, grid, steps, transport):
     """The multi-GPU schedule of NESTED levels (partition.MultiLevelRunner: per-level exchanges posted and joined around the part
     launches, both levels' same-level ghosts, temporal blend) over RCCL on one GPU: two levels on a periodic
@@ -134,12 +134,19 @@ def test_nested_levels_over_rccl_loopback(gpu, tmp_path, grid, steps, transport)
     s.close()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY="0", LOOPBACK_TRANSPORT=transport)
+    # native: levels this small exchange ON their own stream (ludwig_halo_plan_in_stream; partition.MultiLevelRunner's rule);
+    # native-overlap: the rule switched off - every exchange on its plan's stream under the level's interior part
+    if transport == "native-overlap":
+        transport = env["LOOPBACK_TRANSPORT"] = "native"
+        env["LUDWIG_HALO_IN_STREAM_BELOW"] = "0"
     out = tmp_path / "rep.json"
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_loopback_worker.py"), grid, "4", str(steps), str(out), "nested"],
                          capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     rep = json.load(open(out))
     assert rep["backend"] == "nccl" and rep["transport"] == transport and rep["nested"]
+    if transport == "native":
+        assert rep["exchange_in_stream"] == [env.get("LUDWIG_HALO_IN_STREAM_BELOW") != "0"] * 2
     assert rep["owned"] == [64, 256] and all(b > 0 for b in rep["halo_bytes_per_level"])
     # what this construction cannot reach: parent-data ghosts. An interface stencil crosses a cut only if the refined region ends AT the
     # cut, and there the reference's edge chain (global coordinates, no wrap) gives the one-brick box an inlet where the G-brick box
