@@ -2433,9 +2433,13 @@ int ludwig_step_distributed(LudwigLevel *L, LudwigHaloPlan *P, const LudwigLevel
         // the correction rewrites f_out from post-collision values of neighbour cells (src/bouzidi_kernel.jl:44-77): the few that
         // live across a cut are fetched in between, and waited for
         if (P->g[2].n_send || P->g[2].n_recv) {
+            // a few thousand elements, needed at once: on the level's own stream (two cross-stream hand-overs cost more than the messages)
             const int32_t grp = 2, fld = LUDWIG_F_POST;
-            if ((rc = ludwig_halo_exchange(P, 1, &grp, &fld))) return rc;
-            if ((rc = ludwig_halo_wait(P))) return rc;
+            const bool mode = P->in_stream;
+            P->in_stream = true;
+            rc = ludwig_halo_exchange(P, 1, &grp, &fld);
+            P->in_stream = mode;
+            if (rc) return rc;
         }
         if ((rc = launch_bouzidi(L, t_sub, fl->q_min_threshold))) return rc;
     }

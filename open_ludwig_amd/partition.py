@@ -1074,6 +1074,22 @@ class MultiLevelRunner:
         if self.ex[i] is not None:
             self.ex[i].post(fields)
 
+    def _post_and_join_now(self, i: int, fields: Dict[str, str]) -> None:
+        """an exchange whose result is needed at once (the f_post halo before the Bouzidi correction): nothing can run under it, so the
+        native transport queues it on the level's own stream - no hand-over to the plan's stream and back"""
+        ex = self.ex[i]
+        if ex is None:
+            return
+        if isinstance(ex, NativeHalo) and not ex.in_stream:
+            ex.set_in_stream(True)           # (joins an exchange still in flight first)
+            try:
+                ex.post(fields)
+            finally:
+                ex.set_in_stream(False)
+            return
+        ex.post(fields)
+        ex.join()
+
     def _step_level(self, i: int, t_sub: int, parent, parent_tau, tw, u, has_children: bool) -> None:
         """One level step + its halo exchange (same-level ghosts and the parent-data ghosts of peers' finer blocks).
         Overlap (the exchange runs on its own stream):
@@ -1098,8 +1114,7 @@ class MultiLevelRunner:
             if stepping:
                 stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_ALL)
             if has_post_halo:
-                self._post(i, {"f_post": "f_post_collision"})
-                self._join(i)
+                self._post_and_join_now(i, {"f_post": "f_post_collision"})
             if stepping and L.has_post_collision:
                 apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
             self._post(i, fields)
@@ -1121,8 +1136,7 @@ class MultiLevelRunner:
         if stepping:
             stream_collide(L, parent, parent_tau, u, self.params, t_sub, tw, part=_lib.PART_BOUNDARY)
         if has_post_halo:
-            self._post(i, {"f_post": "f_post_collision"})
-            self._join(i)
+            self._post_and_join_now(i, {"f_post": "f_post_collision"})
         if bouzidi:
             apply_bouzidi_correction(L, t_sub, self.params.q_min_threshold)
         self._post(i, fields)
