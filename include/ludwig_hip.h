@@ -141,7 +141,9 @@ int  ludwig_level_add_post_collision_readers(LudwigLevel *level, const int64_t *
  * send/recv, ludwig_halo_unpack on other streams). A stream-collide launch fills every CU, and a send/recv kernel queued beside
  * it - even on a high-priority stream - is handed its workgroups only as the launch drains (measured: 20 us alone, 470 us beside
  * it). Compute units the stepping stream never uses are free the moment the exchange needs them; the step is HBM-bound and does
- * not miss them. The reserved CUs are spread evenly over the XCDs. No reference counterpart (single GPU); hipStream_t in *stream_out.
+ * not miss them. The reserved CUs are spread evenly over the XCDs AND over the four shader engines of every XCD (an unbalanced mask costs the
+ * step more than a larger balanced one): on a 256-CU device the request is rounded up to a multiple of 32. No reference counterpart (single GPU);
+ * hipStream_t in *stream_out.
  */
 int  ludwig_stream_create(int device, int reserved_cus, void **stream_out);
 int  ludwig_stream_destroy(int device, void *hip_stream);

@@ -1405,17 +1405,16 @@ int ludwig_stream_create(int device, int reserved_cus, void **stream_out)
     if (reserved_cus > n_cu / 2) return fail(LUDWIG_ERR_INVALID, "%d of %d compute units reserved: at most half", reserved_cus, n_cu);
     std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
     for (int i = 0; i < n_cu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-    // Bit i of the mask is a CU of XCD i mod 8 (measured, tools/cu_mask_patterns.py: bits 0, 32, ..., 224 off cost the
-    // plane-per-XCD work lists 18 %, any one-per-XCD choice a flat 4.7 % - the price of a non-full mask, however few CUs it
-    // leaves out). Bits 33 j + 8 m (j = 0..7) take one CU per XCD per group of 8 - and would also be balanced if the bits
-    // were numbered XCD by XCD (256 CUs in 8 XCDs; other sizes: evenly spaced bits).
+    // Bit i of the mask is a CU of XCD i mod 8, and inside an XCD four consecutive CU indices sit in its four shader engines
+    // (measured, tools/cu_mask_patterns.py, profiles/r03_cu_mask_patterns.txt: CUs 0, 8, 16, 24 of every XCD off = +51 %, CUs 0-3 of
+    // every XCD off = +4.5 %; one CU per XCD off = +6 %, a single CU = +8 %). What a mask costs the stepping kernel is the IMBALANCE between
+    // shader engines, not the number of CUs: the cheapest mask that reserves anything takes one CU out of every shader engine of every
+    // XCD - 32 mask bits - and costs less than round 2's one-per-XCD pattern. So on 256 CUs the request is rounded up to a multiple of 32
+    // (bits 224-255, then 192-223, ...; 64 CUs: +12.6 %).
     int done = 0;
     if (n_cu == 256) {
-        for (int m = 0; done < reserved_cus && m < 4; ++m)
-            for (int j = 0; j < 8 && done < reserved_cus; ++j, ++done) {
-                const int bit = 33 * j + 8 * m;
-                mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
-            }
+        const int groups = (reserved_cus + 31) / 32;
+        for (int bit = 256 - 32 * groups; bit < 256; ++bit, ++done) mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
     }
     for (int k = 0; done < reserved_cus; ++k) {      // generic / remainder: evenly spaced, skipping bits already cleared
         const int bit = (int)(((int64_t)k * n_cu) / reserved_cus + 5) % n_cu;

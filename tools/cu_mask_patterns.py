@@ -22,6 +22,13 @@ pats = {
     "bits 224-255 off": mask_without(range(224, 256)),
     "bits 0,1 off": mask_without([0, 1]),
     "bit 0 off": mask_without([0]),
+    # round 3: is the price the NUMBER of compute units or an imbalance between the shader engines of an XCD?
+    "bits 0-31 off (CUs 0-3 of every XCD)": mask_without(range(32)),
+    "bits 0-15 off (CUs 0-1 of every XCD)": mask_without(range(16)),
+    "bits 192-255 off (CUs 24-31 of every XCD)": mask_without(range(192, 256)),
+    "bits 0-7 + 64-71 + 128-135 + 192-199 off (CUs 0, 8, 16, 24)": mask_without([b + o for o in (0, 64, 128, 192) for b in range(8)]),
+    "bits 0-7 + 8-15 off again as 16": mask_without(range(16)),
+    "bits 224-255 off again": mask_without(range(224, 256)),
     "null stream again": None,
 }
 for name, m in pats.items():
