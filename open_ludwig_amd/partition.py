@@ -646,9 +646,12 @@ class DistributedLevelRunner:
         name_post_collision_readers(view.level, plan)
         self.level = adapt(view.level, device)
         self.dev = torch.device("cuda", device)
-        # overlap: the stepping stream leaves a few compute units to the exchange (include/ludwig_hip.h: ludwig_stream_create;
-        # LUDWIG_COMM_RESERVED_CUS, 0 = none); pack / unpack and RCCL run on a high-priority stream
-        self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "8")) if overlap else 0
+        # overlap: the stepping stream leaves compute units to the exchange (include/ludwig_hip.h: ludwig_stream_create;
+        # LUDWIG_COMM_RESERVED_CUS, 0 = none); pack / unpack and RCCL run on a high-priority stream. 32 = one CU out of every shader
+        # engine of every XCD: the cheapest mask there is (the library rounds any request up to that, profiles/r03_cu_mask_patterns.txt)
+        self.reserved_cus = int(os.environ.get("LUDWIG_COMM_RESERVED_CUS", "32")) if overlap else 0
+        if self.reserved_cus > 0:
+            self.reserved_cus = -(-self.reserved_cus // 32) * 32          # what ludwig_stream_create makes of it on 256 CUs
         self._own_streams = []
         if overlap and self.reserved_cus > 0:
             ptr = C.c_void_p()
