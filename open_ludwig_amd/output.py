@@ -34,11 +34,26 @@ def _encode(a: np.ndarray, compress: bool) -> str:
     raw = np.ascontiguousarray(a).tobytes()
     if not compress:
         return (base64.b64encode(np.uint64(len(raw)).tobytes()) + base64.b64encode(raw)).decode()
-    blocks = [raw[i:i + _ZBLOCK] for i in range(0, len(raw), _ZBLOCK)] or [b""]
-    comp = [zlib.compress(b, 6) for b in blocks]
-    last = len(blocks[-1]) if len(blocks[-1]) != _ZBLOCK else 0
-    head = np.array([len(blocks), _ZBLOCK, last] + [len(c) for c in comp], dtype=np.uint64)
+    view = memoryview(raw)
+    starts = range(0, len(raw), _ZBLOCK) if len(raw) else [0]
+    n_blocks = len(starts)
+    if len(raw) > (64 << 20):        # a shipped-size flow mesh is 9 GB of arrays: zlib releases the GIL, the blocks are independent
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=_zlib_threads()) as pool:
+            comp = list(pool.map(lambda i: zlib.compress(view[i:i + _ZBLOCK], 6), starts, chunksize=256))
+    else:
+        comp = [zlib.compress(view[i:i + _ZBLOCK], 6) for i in starts]
+    tail = len(raw) - (n_blocks - 1) * _ZBLOCK
+    last = tail if tail != _ZBLOCK else 0
+    head = np.array([n_blocks, _ZBLOCK, last] + [len(c) for c in comp], dtype=np.uint64)
     return (base64.b64encode(head.tobytes()) + base64.b64encode(b"".join(comp))).decode()
+
+
+def _zlib_threads() -> int:
+    try:
+        return max(1, min(32, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(32, os.cpu_count() or 1))
 
 
 def _data_array(name: str, a: np.ndarray, compress: bool, ncomp: int = 1) -> str:
@@ -112,16 +127,32 @@ def build_flow_mesh(t_step: int, grids, fields) -> Dict[str, np.ndarray]:
     level = np.empty((n_total, n_cells), dtype=np.int32)
     pz, py, px = np.meshgrid(np.arange(B + 1), np.arange(B + 1), np.arange(B + 1), indexing="ij")      # px fastest
     pxyz = np.stack([px.reshape(-1), py.reshape(-1), pz.reshape(-1)], axis=1).astype(np.float32)
-    for i, (lvl, b) in enumerate(valid):
+    lv_of = np.array([l for l, _ in valid], dtype=np.int64)
+    blk_of = np.array([b for _, b in valid], dtype=np.int64)
+
+    def cells_of(a, blocks):
+        """[8,8,8,nb(,K)] -> [len(blocks), 512(, K)] with the cell index x fastest; whole 512-cell chunks when the array is Fortran-ordered"""
+        if a.flags.f_contiguous:
+            nb = a.shape[3]
+            if a.ndim == 4:
+                return np.take(a.T.reshape(nb, n_cells), blocks, axis=0)
+            return np.take(a.T.reshape(a.shape[4], nb, n_cells), blocks, axis=1).transpose(1, 2, 0)
+        sub = a[:, :, :, blocks]
+        if a.ndim == 4:
+            return sub.reshape(n_cells, len(blocks), order="F").T
+        return sub.reshape(n_cells, len(blocks), a.shape[4], order="F").transpose(1, 0, 2)
+
+    for lvl in sorted(data):                                         # a level at a time (the valid list is level-major, blocks ascending)
         r, v, o, dx = data[lvl]
-        bc = np.asarray(grids[lvl].active_block_coords[b], dtype=np.int64)
+        rows = np.flatnonzero(lv_of == lvl)
+        blocks = blk_of[rows]
+        bc = np.asarray(grids[lvl].active_block_coords, dtype=np.int64)[blocks]
         off = ((bc - 1) * B).astype(np.float32)
-        points[i] = (off[None, :] + pxyz) * dx                       # (off + p) * dx in Float32, as the reference
-        rho[i] = r[:, :, :, b].reshape(-1, order="F")                 # cell order x fastest
-        for c in range(3):
-            vel[i, :, c] = v[:, :, :, b, c].reshape(-1, order="F")
-        obst[i] = o[:, :, :, b].reshape(-1, order="F")
-        level[i] = lvl + 1
+        points[rows] = (off[:, None, :] + pxyz[None, :, :]) * dx      # (off + p) * dx in Float32, as the reference
+        rho[rows] = cells_of(r, blocks)                               # cell order x fastest
+        vel[rows] = cells_of(v, blocks)
+        obst[rows] = cells_of(o, blocks)
+        level[rows] = lvl + 1
     z, y, x = np.meshgrid(np.arange(B), np.arange(B), np.arange(B), indexing="ij")
     sy, sz = B + 1, (B + 1) ** 2
     base = (x + y * sy + z * sz).reshape(-1)
