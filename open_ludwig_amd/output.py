@@ -73,9 +73,9 @@ def write_vtu(filename: str, points: np.ndarray, connectivity: np.ndarray, offse
         io.write(f'<Piece NumberOfPoints="{points.shape[0]}" NumberOfCells="{types.shape[0]}">\n')
         io.write("<Points>\n" + _data_array("Points", points, compress, 3) + "</Points>\n")
         io.write("<Cells>\n")
-        io.write(_data_array("connectivity", connectivity.astype(np.int64), compress))
-        io.write(_data_array("offsets", offsets.astype(np.int64), compress))
-        io.write(_data_array("types", types.astype(np.uint8), compress))
+        io.write(_data_array("connectivity", np.asarray(connectivity, dtype=np.int64), compress))       # (no copy when already Int64)
+        io.write(_data_array("offsets", np.asarray(offsets, dtype=np.int64), compress))
+        io.write(_data_array("types", np.asarray(types, dtype=np.uint8), compress))
         io.write("</Cells>\n<CellData>\n")
         for name, a in cell_data:
             io.write(_data_array(name, a, compress, 1 if a.ndim == 1 else a.shape[1]))
@@ -161,8 +161,8 @@ def build_flow_mesh(t_step: int, grids, fields) -> Dict[str, np.ndarray]:
     conn = (conn_block[None, :, :] + (np.arange(n_total) * n_pts)[:, None, None]).reshape(-1)
     vel = _scrub(vel.reshape(-1, 3))
     return {
-        "points": points.reshape(-1, 3), "connectivity": conn.astype(np.int64),
-        "offsets": (np.arange(1, n_total * n_cells + 1) * 8).astype(np.int64),
+        "points": points.reshape(-1, 3), "connectivity": np.asarray(conn, dtype=np.int64),
+        "offsets": np.arange(8, 8 * (n_total * n_cells + 1), 8, dtype=np.int64),
         "types": np.full(n_total * n_cells, VTK_VOXEL, dtype=np.uint8),
         "Density": _scrub(rho.reshape(-1)), "Velocity": vel,
         "VelocityMagnitude": np.sqrt(vel[:, 0] ** 2 + vel[:, 1] ** 2 + vel[:, 2] ** 2),
