@@ -15,7 +15,7 @@
  * (tests/test_case_ball1m.py: test_oracle_itself_reproduces_reference_cd_series), and the HIP path
  * gives the same rows bit for bit; the one row that differs in the fourth decimal (step 200:
  * 0.0637 here, 0.0633 in the log) is reproduced by building this same source with FMA contraction,
- * as the reference's CUDA run was (tools/oracle_contraction.py: 0.063311); (ii) the force / convergence histories the reference keeps
+ * as the reference's CUDA run was (tests/oneoff_oracle_contraction.py: 0.063311); (ii) the force / convergence histories the reference keeps
  * under CASES/ball1m/RESULTS (Re 9.87 M, 4 levels): the HIP path, which is bit-identical to
  * this oracle, reproduces them to 1e-5..3e-4 relative in the drag force over 4000 steps;
  * (iii) analytic invariants and bit-level re-derivations (tests/test_oracle_invariants.py).
