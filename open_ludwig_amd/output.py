@@ -21,6 +21,7 @@ from .blocks import BLOCK_SIZE
 
 VTK_VOXEL, VTK_TRIANGLE = 11, 5
 _ZBLOCK = 1 << 15
+_PARALLEL_ABOVE = 64 << 20      # bytes of one array above which its zlib blocks are compressed on all cores
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -37,7 +38,7 @@ def _encode(a: np.ndarray, compress: bool) -> str:
     view = memoryview(raw)
     starts = range(0, len(raw), _ZBLOCK) if len(raw) else [0]
     n_blocks = len(starts)
-    if len(raw) > (64 << 20):        # a shipped-size flow mesh is 9 GB of arrays: zlib releases the GIL, the blocks are independent
+    if len(raw) > _PARALLEL_ABOVE:   # a shipped-size flow mesh is 9 GB of arrays: zlib releases the GIL, the blocks are independent
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=_zlib_threads()) as pool:
             comp = list(pool.map(lambda i: zlib.compress(view[i:i + _ZBLOCK], 6), starts, chunksize=256))

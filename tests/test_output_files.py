@@ -121,3 +121,16 @@ def test_surface_vtu_and_csv_formats(tmp_path):
     lines = open(tmp_path / "loads.csv").read().splitlines()
     assert len(lines) == n + 1 and lines[0].startswith("triangle_id,cx,cy,cz") and lines[1].split(",")[0] == "1"
     assert "Cd = +0.471235" in output.force_summary(fr, 1.225, 4.0, 0.785, 1.0)
+
+
+def test_parallel_zlib_blocks_give_the_same_bytes(monkeypatch):
+    """Arrays above output._PARALLEL_ABOVE bytes have their zlib blocks compressed on a thread pool (the shipped wing's flow file is 9 GB
+    of arrays): block boundaries, order and the header are the serial ones, so the encoded text is identical."""
+    from open_ludwig_amd import output as out
+    rng = np.random.default_rng(5)
+    for n in (0, 1, (1 << 15) // 4, (1 << 15) // 4 + 1, 300_001):
+        a = (rng.random(n) * 100).astype(np.float32)
+        monkeypatch.setattr(out, "_PARALLEL_ABOVE", 1 << 62)
+        serial = out._encode(a, True)
+        monkeypatch.setattr(out, "_PARALLEL_ABOVE", -1)
+        assert out._encode(a, True) == serial, n
